@@ -1,0 +1,220 @@
+"""Synthetic checkpoints and the "FAVW" weight blob that fav_load_weights() takes.
+
+No pretrained weights exist offline and the reference ships none (SURVEY.md
+§8c "Remote loaders"), so checkpoints are generated: He-normal convolutions with
+BatchNorm statistics *calibrated* on a small batch of synthetic frames (as a
+trained network's running statistics would be), then folded into per-output-
+channel scale (multiplied into the weights before the bf16 rounding) and an
+fp32 bias.  Calibrated statistics are quantised to bf16 before folding so the
+resulting blob is bit-identical on any machine (BLAS summation order only moves
+the statistics by ~1e-16 relative); tests pin the blob by checksum.
+
+Blob layout (little endian):
+  header  32 B : u32 magic 'FAVW', u32 version=1, u32 arch, u32 num_classes,
+                 u32 n_layers, u32 reserved[3]
+  table   48 B per layer: u32 cout, cin, kh, kw, stride, pad, reserved[2];
+                 u64 w_off, b_off   (byte offsets from blob start, 64-B aligned)
+  data         : per layer bf16 w[cout][kh][kw][cin] (BN scale folded in),
+                 fp32 b[cout]
+Layer order: stem; per block conv1, conv2, (conv3), (downsample); fc.
+"""
+from __future__ import annotations
+
+import hashlib
+import struct
+
+import numpy as np
+
+from . import synth
+
+BLOB_MAGIC = 0x57564146
+ARCH_IDS = {"resnet18_cifar": 0, "resnet50": 1}
+_ARCH = {
+    0: dict(block="basic", depths=(2, 2, 2, 2), planes=(64, 128, 256, 512), stem="cifar", calib_hw=32),
+    1: dict(block="bottleneck", depths=(3, 4, 6, 3), planes=(64, 128, 256, 512), stem="imagenet", calib_hw=96),
+}
+DEFAULT_MEAN = (0.485, 0.456, 0.406)
+DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+def layer_specs(arch: int, num_classes: int):
+    """Blob-order list of dict(cout, cin, kh, kw, stride, pad, role, block)."""
+    a = _ARCH[arch]
+    L = []
+    if a["stem"] == "imagenet":
+        L.append(dict(cout=64, cin=3, kh=7, kw=7, stride=2, pad=3, role="stem", block=-1))
+    else:
+        L.append(dict(cout=64, cin=3, kh=3, kw=3, stride=1, pad=1, role="stem", block=-1))
+    exp = 4 if a["block"] == "bottleneck" else 1
+    inpl, bidx = 64, 0
+    for li, (d, p) in enumerate(zip(a["depths"], a["planes"])):
+        for bi in range(d):
+            s = 2 if (bi == 0 and li > 0) else 1
+            if a["block"] == "bottleneck":
+                L.append(dict(cout=p, cin=inpl, kh=1, kw=1, stride=1, pad=0, role="mid", block=bidx))
+                L.append(dict(cout=p, cin=p, kh=3, kw=3, stride=s, pad=1, role="mid", block=bidx))
+                L.append(dict(cout=p * 4, cin=p, kh=1, kw=1, stride=1, pad=0, role="last", block=bidx))
+            else:
+                L.append(dict(cout=p, cin=inpl, kh=3, kw=3, stride=s, pad=1, role="mid", block=bidx))
+                L.append(dict(cout=p, cin=p, kh=3, kw=3, stride=1, pad=1, role="last", block=bidx))
+            if bi == 0 and (s != 1 or inpl != p * exp):
+                L.append(dict(cout=p * exp, cin=inpl, kh=1, kw=1, stride=s, pad=0, role="down", block=bidx))
+            inpl = p * exp
+            bidx += 1
+    L.append(dict(cout=num_classes, cin=inpl, kh=1, kw=1, stride=1, pad=0, role="fc", block=bidx))
+    return L
+
+
+def n_blocks(arch: int) -> int:
+    return sum(_ARCH[arch]["depths"])
+
+
+def site_mask_for(arch: int, policy: str) -> int:
+    """Dropout-site bitmask.  Site s < n_blocks is the output of residual block
+    s; site n_blocks is the pooled feature vector feeding the classifier."""
+    nb = n_blocks(arch)
+    if policy in ("none", "", None):
+        return 0
+    if policy == "last_layer":
+        return 1 << nb
+    if policy == "all_blocks":
+        return (1 << nb) - 1
+    if policy == "layer4+fc":
+        d = _ARCH[arch]["depths"]
+        first = nb - d[-1] - 1  # output of the block feeding the last stage
+        m = 1 << nb
+        for s in range(first, nb - 1):
+            m |= 1 << s
+        return m
+    raise ValueError(f"unknown dropout policy {policy!r}")
+
+
+def _bf16(x):
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _bf16_f32(x):
+    return (_bf16(x).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(x))
+
+
+def _conv64(x, w, stride, pad):
+    """float64 NHWC conv by im2col (calibration only)."""
+    b, h, ww, c = x.shape
+    co, kh, kw, _ = w.shape
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (ww + 2 * pad - kw) // stride + 1
+    xp = np.zeros((b, h + 2 * pad, ww + 2 * pad, c))
+    xp[:, pad:pad + h, pad:pad + ww] = x
+    sb, sh, sw, sc = xp.strides
+    cols = np.lib.stride_tricks.as_strided(
+        xp, (b, ho, wo, kh, kw, c), (sb, sh * stride, sw * stride, sh, sw, sc), writeable=False)
+    return (cols.reshape(b * ho * wo, -1) @ w.reshape(co, -1).T.astype(np.float64)).reshape(b, ho, wo, co)
+
+
+def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = None,
+                   mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 6.0, n_calib: int = 16):
+    """Returns (blob bytes, info dict)."""
+    arch = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
+    a = _ARCH[arch]
+    if num_classes is None:
+        num_classes = 1000 if arch == 1 else 10
+    specs = layer_specs(arch, num_classes)
+    rng = np.random.default_rng([int(seed), arch, 0x77])
+    hw = a["calib_hw"]
+    frames = synth.synthetic_frames_u8(n_calib, hw, hw, seed=0xCA11B, start_id=0)
+    # half of the calibration frames carry Gaussian noise (severities 1..5) so the
+    # statistics also cover the corrupted regime the detector is meant for
+    x01 = frames.astype(np.float64) / 255.0
+    for i in range(n_calib // 2, n_calib):
+        x01[i] = synth.gaussian_noise_f32(frames[i:i + 1], 1 + i % 5, seed=0xCA11B, start_id=i)[0]
+    x = (x01 - np.asarray(mean)) / np.asarray(std)
+
+    folded = []  # (w_bf16_bits, b_fp32)
+
+    def make_layer(spec, inp):
+        fan_in = spec["kh"] * spec["kw"] * spec["cin"]
+        gain = 1.0 if spec["role"] == "down" else 2.0
+        w = rng.standard_normal((spec["cout"], spec["kh"], spec["kw"], spec["cin"])) * np.sqrt(gain / fan_in)
+        acc = _conv64(inp, w, spec["stride"], spec["pad"])
+        mu = _bf16_f32(acc.mean(axis=(0, 1, 2))).astype(np.float64)
+        var = _bf16_f32(acc.var(axis=(0, 1, 2))).astype(np.float64)
+        gamma = {"stem": 1.0, "mid": 1.0, "last": 0.25, "down": 0.7}[spec["role"]]
+        gam = gamma * (1.0 + 0.1 * rng.standard_normal(spec["cout"]))
+        beta = (0.25 if spec["role"] in ("stem", "mid") else 0.1) * rng.standard_normal(spec["cout"])
+        scale = gam / np.sqrt(var + 1e-5)
+        wq = _bf16((w * scale[:, None, None, None]).astype(np.float32))
+        bq = (beta - mu * scale).astype(np.float32)
+        wf = (wq.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        out = _conv64(inp, wf, spec["stride"], spec["pad"]) + bq.astype(np.float64)
+        folded.append((wq, bq))
+        return out
+
+    it = iter(specs)
+    spec = next(it)
+    act = np.maximum(make_layer(spec, x), 0.0)
+    if a["stem"] == "imagenet":  # 3x3/2 max pool, pad 1
+        b_, h_, w_, c_ = act.shape
+        ho, wo = (h_ - 1) // 2 + 1, (w_ - 1) // 2 + 1
+        xp = np.full((b_, h_ + 2, w_ + 2, c_), -np.inf)
+        xp[:, 1:1 + h_, 1:1 + w_] = act
+        act = np.max(np.stack([xp[:, r:r + 2 * ho:2, s:s + 2 * wo:2] for r in range(3) for s in range(3)]), axis=0)
+    nmain = 3 if a["block"] == "bottleneck" else 2
+    spec = next(it)
+    while spec["role"] != "fc":
+        blk = spec["block"]
+        h = act
+        main = [spec] + [next(it) for _ in range(nmain - 1)]
+        for sp in main[:-1]:
+            h = np.maximum(make_layer(sp, h), 0.0)
+        branch = make_layer(main[-1], h)
+        spec = next(it)
+        idn = act
+        if spec["role"] == "down" and spec["block"] == blk:
+            idn = make_layer(spec, act)
+            spec = next(it)
+        act = np.maximum(branch + idn, 0.0)
+    feat = act.mean(axis=(1, 2))  # [n_calib, C]
+    # classifier: zero-mean rows (cancels the common-mode of the all-positive
+    # features), gain chosen so calibration logits have the requested spread,
+    # bias chosen so no class wins by default.
+    w = rng.standard_normal((num_classes, feat.shape[1]))
+    w -= w.mean(axis=1, keepdims=True)
+    raw = (feat - feat.mean(axis=0, keepdims=True)) @ w.T
+    g = float(_bf16_f32(np.float32(logit_std / max(raw.std(), 1e-12))))
+    wq = _bf16((w * g).astype(np.float32))
+    wf = (wq.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    fmean = _bf16_f32(feat.mean(axis=0)).astype(np.float64)
+    bq = (-(fmean @ wf.T)).astype(np.float32)
+    folded.append((wq.reshape(num_classes, 1, 1, -1), bq))
+
+    blob = pack_blob(arch, num_classes, specs, folded)
+    info = dict(arch=arch, num_classes=num_classes, n_layers=len(specs), seed=seed,
+                sha256=hashlib.sha256(blob).hexdigest(), mean=tuple(mean), std=tuple(std))
+    return blob, info
+
+
+def pack_blob(arch: int, num_classes: int, specs, folded) -> bytes:
+    n = len(specs)
+    off = 32 + 48 * n
+    off = (off + 63) // 64 * 64
+    table, chunks = [], []
+    for sp, (wq, bq) in zip(specs, folded):
+        wb = np.ascontiguousarray(wq, np.uint16).tobytes()
+        w_off = off
+        off = (off + len(wb) + 63) // 64 * 64
+        bb = np.ascontiguousarray(bq, np.float32).tobytes()
+        b_off = off
+        off = (off + len(bb) + 63) // 64 * 64
+        table.append(struct.pack("<8I2Q", sp["cout"], sp["cin"], sp["kh"], sp["kw"], sp["stride"], sp["pad"], 0, 0,
+                                 w_off, b_off))
+        chunks.append((w_off, wb))
+        chunks.append((b_off, bb))
+    buf = bytearray(off)
+    struct.pack_into("<8I", buf, 0, BLOB_MAGIC, 1, arch, num_classes, n, 0, 0, 0)
+    for i, t in enumerate(table):
+        buf[32 + 48 * i:32 + 48 * (i + 1)] = t
+    for o, b in chunks:
+        buf[o:o + len(b)] = b
+    return bytes(buf)

@@ -1,0 +1,150 @@
+"""PyTorch-CPU port of the oracle (same numerical contract as fav_oracle.py).
+
+TEST INFRASTRUCTURE ONLY — PARITY UNPINNED (see fav_oracle.py header).
+
+Two jobs: (1) an independent cross-check of the NumPy restatement against
+``torch.nn.functional`` (conv2d, max_pool2d, linear, softmax), so the oracle is
+not self-referential (SURVEY.md §8c "Therefore the oracle is"); (2) the
+``cpu_baseline`` leg of bench.py (kind "port": multithreaded MKL-DNN fp32 on
+the host cores), which is the strongest CPU implementation available here.
+
+Never imported by ``failure_aware_vision_amd``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import fav_oracle as O
+
+
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class TorchNet:
+    def __init__(self, model: O.Model):
+        self.m = model
+        self.cfg = O.arch_cfg(model.arch)
+        conv = lambda L: (torch.from_numpy(np.ascontiguousarray(L.w.transpose(0, 3, 1, 2))).contiguous(
+            memory_format=torch.channels_last), torch.from_numpy(L.b), L.stride, L.pad)
+        self.stem_l = conv(model.layers[0])
+        self.blocks = []
+        idx = 1
+        for nmain, ds in O.block_table(model.arch):
+            main = [conv(L) for L in model.layers[idx:idx + nmain]]; idx += nmain
+            down = None
+            if ds:
+                down = conv(model.layers[idx]); idx += 1
+            self.blocks.append((main, down))
+        fc = model.layers[idx]
+        self.fc_w = torch.from_numpy(fc.w.reshape(fc.cout, -1).copy())
+        self.fc_b = torch.from_numpy(fc.b)
+        self.nb = len(self.blocks)
+
+    @staticmethod
+    def _conv(x, L, res=None, relu=True, keep=None, scale=1.0):
+        w, b, stride, pad = L
+        y = F.conv2d(x, w, None, stride, pad) + b.view(1, -1, 1, 1)
+        if res is not None:
+            y = y + res
+        if relu:
+            y = torch.relu(y)
+        if keep is not None:
+            y = torch.where(keep, y * scale, torch.zeros((), dtype=torch.float32))
+        return _bf16(y)
+
+    def stem(self, xn):
+        y = self._conv(xn, self.stem_l)
+        if self.cfg["stem"] == "imagenet":
+            y = F.max_pool2d(y, 3, 2, 1)
+        return y
+
+    def block(self, i, x, keep=None, scale=1.0):
+        main, down = self.blocks[i]
+        h = x
+        for L in main[:-1]:
+            h = self._conv(h, L)
+        idn = x if down is None else self._conv(x, down, relu=False)
+        return self._conv(h, main[-1], res=idn, keep=keep, scale=scale)
+
+    def pool_fc(self, x, keep=None, scale=1.0):
+        b, c, h, w = x.shape
+        acc = torch.zeros(b, c)
+        for i in range(h):
+            for j in range(w):
+                acc = acc + x[:, :, i, j]
+        y = acc * float(np.float32(1.0 / (h * w)))
+        if keep is not None:
+            y = torch.where(keep, y * scale, torch.zeros((), dtype=torch.float32))
+        return F.linear(_bf16(y), self.fc_w, self.fc_b)
+
+    @staticmethod
+    def _keep_nchw(seed, t, site, img_ids, shape_nchw, thr):
+        b, c, h, w = shape_nchw
+        k = O.dropout_keep(seed, t, site, img_ids, h * w * c, thr).reshape(b, h, w, c)
+        return torch.from_numpy(np.ascontiguousarray(k.transpose(0, 3, 1, 2)))
+
+    @torch.no_grad()
+    def forward_logits(self, xn_nhwc: np.ndarray, img_ids=None, n_samples=1, site_mask=0, p=0.0, seed=0):
+        x = torch.from_numpy(np.ascontiguousarray(xn_nhwc.transpose(0, 3, 1, 2))).contiguous(
+            memory_format=torch.channels_last)
+        b = x.shape[0]
+        img_ids = np.arange(b) if img_ids is None else np.asarray(img_ids)
+        thr = O.dropout_threshold(p)
+        if site_mask == 0 or thr == 0:
+            site_mask, n_samples, thr = 0, 1, 0
+        scale = float(O.dropout_scale(thr))
+        first = min((s for s in range(self.nb + 1) if site_mask >> s & 1), default=self.nb + 1)
+
+        def out_shape(i, act):
+            main, _ = self.blocks[i]
+            h, w = act.shape[2], act.shape[3]
+            for (wt, _, s, pd) in main:
+                h = (h + 2 * pd - wt.shape[2]) // s + 1
+                w = (w + 2 * pd - wt.shape[3]) // s + 1
+            return (act.shape[0], main[-1][0].shape[0], h, w)
+
+        def run_from(stage, act, t):
+            for i in range(stage, self.nb):
+                keep = None
+                if site_mask >> i & 1:
+                    keep = self._keep_nchw(seed, t, i, img_ids, out_shape(i, act), thr)
+                act = self.block(i, act, keep, scale)
+            keep = None
+            if site_mask >> self.nb & 1:
+                keep = torch.from_numpy(O.dropout_keep(seed, t, self.nb, img_ids, act.shape[1], thr))
+            return self.pool_fc(act, keep, scale)
+
+        act = self.stem(x)
+        if first > self.nb:
+            return run_from(0, act, 0)[None].numpy()
+        npre = min(first + 1, self.nb)
+        for i in range(npre):
+            act = self.block(i, act)
+        outs = []
+        for t in range(n_samples):
+            a = act
+            if first < self.nb:
+                keep = self._keep_nchw(seed, t, first, img_ids, tuple(a.shape), thr)
+                a = _bf16(torch.where(keep, a * scale, torch.zeros((), dtype=torch.float32)))
+            outs.append(run_from(npre, a, t))
+        return torch.stack(outs).numpy()
+
+
+def classify(model: O.Model, images: np.ndarray, cfg: O.ClassifyConfig, img_ids=None, return_logits=False, net=None):
+    net = net or TorchNet(model)
+    xn = O.normalize_input(images, cfg.mean, O.inv_std32(cfg.std))
+    lg = net.forward_logits(xn, img_ids, cfg.n_samples, cfg.site_mask, cfg.p, cfg.seed)
+    z = torch.from_numpy(lg) * float(np.float32(1.0 / cfg.temperature))
+    pbar = torch.softmax(z, dim=-1).mean(dim=0).numpy()
+    labels = pbar.argmax(axis=-1).astype(np.int32)
+    if cfg.conf_kind == O.CONF_MAX_SOFTMAX:
+        conf = pbar.max(axis=-1)
+    else:
+        pl = np.where(pbar > 0, pbar * np.log(np.maximum(pbar, 1e-45)), 0.0).astype(np.float32)
+        conf = 1.0 - (-pl.sum(axis=-1)) / np.float32(np.log(pbar.shape[-1]))
+    if return_logits:
+        return labels, conf.astype(np.float32), lg, pbar
+    return labels, conf.astype(np.float32)

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def r18_blob():
+    from failure_aware_vision_amd import weights
+    return weights.make_synthetic("resnet18_cifar", seed=1)
+
+
+@pytest.fixture(scope="session")
+def r50_blob():
+    from failure_aware_vision_amd import weights
+    return weights.make_synthetic("resnet50", seed=1)
