@@ -1,0 +1,188 @@
+"""Host side of the drop-in: ``Backend.classify(images) -> (labels, confidences)``.
+
+Mirrors the reference's scorer interface so it plugs into the same seam:
+
+* construction per connection / ``reset()`` / drop on disconnect —
+  platform/backend/main.py:110-118, :284-291, :310-317;
+* ``analyze_frame(frame) -> {'anomaly_score', 'vision_status', 'metrics'}`` —
+  the shape of SignalAnalyzer.analyze_frame, platform/backend/signal_analyzer.py:47-143,
+  whose result is fed to ``TrustEngine.update(vision_status, anomaly_score, dt)``
+  (main.py:160-168);
+* errors are reported the reference's way at the seam: ``analyze_frame`` returns
+  ``anomaly_score=None`` on failure, which the engine tolerates
+  (trust_engine.py:101-103,193); ``classify`` itself raises.
+
+All arithmetic happens in the HIP library behind include/fav.h.  torch is used
+only for device buffers and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, weights as _weights
+
+_ARCH = {"resnet18_cifar": _lib.ARCH_RESNET18_CIFAR, "resnet50": _lib.ARCH_RESNET50}
+_CONF = {"max_softmax": _lib.CONF_MAX_SOFTMAX, "entropy": _lib.CONF_ENTROPY}
+_MATH = {"bf16": _lib.MATH_BF16, "f32_exact": _lib.MATH_F32_EXACT}
+
+
+class Backend:
+    def __init__(self, arch: str = "resnet50", blob: bytes | None = None, *, seed_weights: int = 1, device: int | None = None,
+                 in_hw=None, max_batch: int = 256, num_classes: int | None = None,
+                 n_samples: int = 1, dropout_policy: str = "none", dropout_p: float = 0.0, seed: int = 0,
+                 site_mask: int | None = None, temperature: float = 1.0, conf_kind: str = "max_softmax",
+                 tau: float = 0.5, math_mode: str = "bf16", mean=None, std=None,
+                 chunk_a: int = 0, chunk_b: int = 0, regroup_block: int = -1):
+        import torch
+        self._torch = torch
+        self._h = None
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("failure_aware_vision_amd.Backend needs a gfx950 GPU (torch.cuda.is_available() is "
+                               "False); the path has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.arch = arch
+        cfg = _lib.FavConfig()
+        self.lib.fav_default_config(C.byref(cfg), _ARCH[arch])
+        cfg.device = self.device
+        if in_hw is not None:
+            cfg.in_h, cfg.in_w = int(in_hw[0]), int(in_hw[1])
+        if num_classes is not None:
+            cfg.num_classes = int(num_classes)
+        cfg.max_batch = int(max_batch)
+        if mean is not None:
+            cfg.mean[:] = [float(m) for m in mean]
+        if std is not None:
+            cfg.stdev[:] = [float(s) for s in std]
+        cfg.n_samples = int(n_samples)
+        cfg.site_mask = int(site_mask) if site_mask is not None else _weights.site_mask_for(_ARCH[arch], dropout_policy)
+        cfg.dropout_p = float(dropout_p)
+        cfg.seed = int(seed)
+        cfg.temperature = float(temperature)
+        cfg.conf_kind = _CONF[conf_kind]
+        cfg.tau = float(tau)
+        cfg.math_mode = _MATH[math_mode]
+        cfg.chunk_a, cfg.chunk_b, cfg.regroup_block = int(chunk_a), int(chunk_b), int(regroup_block)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self.lib.fav_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        if blob is None:
+            blob, self.weights_info = _weights.make_synthetic(arch, seed=seed_weights, num_classes=cfg.num_classes)
+        self.load_weights(blob)
+        self.mc = cfg.site_mask != 0 and round(cfg.dropout_p * 65536) > 0
+        self.T = cfg.n_samples if self.mc else 1
+        self._prev_status_provider = None
+
+    # -- lifecycle ------------------------------------------------------------
+    def load_weights(self, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _lib.check(self.lib.fav_load_weights(self._h, buf, len(blob)), self._h)
+
+    def reset(self):
+        """Scorer reset on mode switch (main.py:222,227,242,288).  The classifier is stateless."""
+
+    def close(self):
+        if self._h is not None:
+            self.lib.fav_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the hot path ------------------------------------------------------------
+    def _layout_of(self, images) -> int:
+        torch = self._torch
+        dt = images.dtype
+        if dt in (torch.uint8, np.uint8):
+            return _lib.LAYOUT_NHWC_U8
+        if dt in (torch.float32, np.float32):
+            return _lib.LAYOUT_NHWC_F32
+        raise TypeError(f"frames must be uint8 or float32 NHWC, got {dt}")
+
+    def _check_shape(self, images):
+        if images.ndim != 4 or images.shape[1] != self.cfg.in_h or images.shape[2] != self.cfg.in_w or images.shape[3] != 3:
+            raise ValueError(f"expected frames of shape (n, {self.cfg.in_h}, {self.cfg.in_w}, 3), got {tuple(images.shape)}")
+
+    def classify_detect(self, images, first_index: int = 0):
+        """-> (labels int32[n], confidences fp32[n], fail uint8[n], anomaly_score fp32[n]).
+        torch CUDA tensors in -> torch CUDA tensors out (asynchronous on the current
+        stream); numpy in -> numpy out (synchronous)."""
+        torch = self._torch
+        self._check_shape(images)
+        layout = self._layout_of(images)
+        n = int(images.shape[0])
+        if isinstance(images, np.ndarray):
+            img = np.ascontiguousarray(images)
+            labels = np.empty(n, np.int32); conf = np.empty(n, np.float32)
+            fail = np.empty(n, np.uint8); score = np.empty(n, np.float32)
+            _lib.check(self.lib.fav_classify_host(self._h, img.ctypes.data, n, layout, int(first_index),
+                                                  labels.ctypes.data, conf.ctypes.data, fail.ctypes.data,
+                                                  score.ctypes.data), self._h)
+            return labels, conf, fail, score
+        if not images.is_cuda or images.device.index != self.device:
+            raise ValueError(f"frames must live on cuda:{self.device}")
+        img = images.contiguous()
+        dev = img.device
+        labels = torch.empty(n, dtype=torch.int32, device=dev)
+        conf = torch.empty(n, dtype=torch.float32, device=dev)
+        fail = torch.empty(n, dtype=torch.uint8, device=dev)
+        score = torch.empty(n, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.lib.fav_classify_ex(self._h, img.data_ptr(), n, layout, int(first_index), labels.data_ptr(),
+                                            conf.data_ptr(), fail.data_ptr(), score.data_ptr(), stream), self._h)
+        return labels, conf, fail, score
+
+    def classify(self, images, first_index: int = 0):
+        """The drop-in: frames -> (labels, confidences)."""
+        labels, conf, _, _ = self.classify_detect(images, first_index)
+        return labels, conf
+
+    def logits(self):
+        """fp32 [T, n, num_classes] logits of the last classify call (torch CUDA tensor)."""
+        torch = self._torch
+        t, n = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.fav_get_logits(self._h, None, C.byref(t), C.byref(n), None), self._h)
+        out = torch.empty((t.value, n.value, self.cfg.num_classes), dtype=torch.float32, device=f"cuda:{self.device}")
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        _lib.check(self.lib.fav_get_logits(self._h, out.data_ptr(), None, None, stream), self._h)
+        return out
+
+    # -- profiling (bench.py roofline leg) ----------------------------------------
+    def set_profiling(self, enable: bool):
+        _lib.check(self.lib.fav_set_profiling(self._h, 1 if enable else 0), self._h)
+
+    def get_profile(self, reset: bool = True) -> dict:
+        p = _lib.FavProfile()
+        _lib.check(self.lib.fav_get_profile(self._h, C.byref(p), 1 if reset else 0), self._h)
+        return {name: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i])
+                for i, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
+
+    # -- the reference seam ----------------------------------------------------------
+    def analyze_frame(self, frame: np.ndarray, status_provider=None) -> dict:
+        """One uint8 HxWx3 frame -> the dict SignalAnalyzer.analyze_frame returns
+        (signal_analyzer.py:128-143): anomaly_score in [0,1] rounded to 6 places and a
+        vision_status string.  The classifier is an ML sensor only: the rule-based
+        status comes from ``status_provider(frame)`` when given, else VISION_OK
+        (ML influence is only active under VISION_OK, trust_engine.py:179,192)."""
+        status = status_provider(frame) if status_provider is not None else "VISION_OK"
+        try:
+            labels, conf, fail, score = self.classify_detect(np.ascontiguousarray(frame)[None])
+        except Exception:  # the seam's convention: no ML score available (trust_engine.py:101-103)
+            return {"anomaly_score": None, "vision_status": status, "metrics": {}}
+        return {
+            "anomaly_score": round(float(score[0]), 6),
+            "vision_status": status,
+            "metrics": {"label": int(labels[0]), "confidence": round(float(conf[0]), 4), "fail": bool(fail[0]),
+                        "samples": self.T},
+        }
+
+
+def anomaly_score_from_confidence(conf):
+    """score = clamp(1 - conf, 0, 1): same [0,1] range contract as signal_analyzer.py:121."""
+    return np.clip(1.0 - np.asarray(conf, np.float32), 0.0, 1.0).astype(np.float32)

@@ -1,0 +1,850 @@
+// fav.hip — executor and C ABI (include/fav.h) of the MI355X-native
+// failure-aware classification path.
+//
+// Host side of the hot path: a static schedule of kernel launches on ONE HIP
+// stream (handle is single-caller, like the reference's per-connection scorer,
+// platform/backend/main.py:110-118), a workspace arena allocated once, and
+// Infinity-Cache-sized passes: frames go through the high-resolution stages in
+// chunks small enough that producer->consumer activations stay in the 256 MiB
+// L3, then through the low-resolution stages in larger chunks that fill the
+// 256 CUs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fav.h"
+#include "fav_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+std::string fmt(const char* f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = fmt("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FAV_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+struct ArchDef {
+    bool bottleneck;
+    int depths[4];
+    int planes[4];
+    bool imagenet_stem;
+};
+const ArchDef kArch[2] = {
+    {false, {2, 2, 2, 2}, {64, 128, 256, 512}, false},
+    {true, {3, 4, 6, 3}, {64, 128, 256, 512}, true},
+};
+
+struct Layer {  // one convolution / fc
+    int cout, cin, kh, kw, stride, pad;
+    int cout_pad, k;         // device layout: w[cout_pad][k], bias[cout_pad]
+    uint16_t* w = nullptr;
+    float* b = nullptr;
+};
+
+enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT };
+enum BufId { B_INPUT = -1, B_PHASE_IN = -2, B_PHASE_OUT = -3, B_NONE = -4, B_A1 = 5 };  // 0..4 rotating
+
+struct Op {
+    OpKind kind;
+    int layer = -1;          // conv layer index
+    int in = B_NONE, out = B_NONE, res = B_NONE;
+    int H = 0, W = 0, C = 0;           // input dims per frame
+    int Ho = 0, Wo = 0, Co = 0;        // output dims per frame
+    int relu = 0, out_f32 = 0;
+    int site = -1;                     // dropout site fused into this op
+    long long in_elems = 0, out_elems = 0;  // per frame
+};
+
+struct Phase {
+    int op_begin, op_end;
+    bool suffix;             // operates on virtual frames (t, i)
+    long long in_elems, out_elems;   // per (virtual) frame
+    int out_bytes_per_elem;
+    bool low_res;            // belongs to the low-resolution group (chunk_b)
+    int chunk;
+};
+
+}  // namespace
+
+struct fav_handle {
+    fav_config cfg;
+    std::string err;
+    int nblocks = 0;
+    std::vector<Layer> layers;
+    std::vector<Op> ops;
+    std::vector<Phase> phases;
+    bool weights_loaded = false;
+    // workspace
+    void* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t act_bytes = 0;
+    void* a1 = nullptr;
+    size_t a1_bytes = 0;
+    std::vector<void*> phase_out;   // output tensor of each phase
+    float* logits = nullptr;        // [T][max_batch][cpad]
+    int cpad = 0;
+    int last_T = 0, last_n = 0;
+    int T_eff = 1;                  // samples actually run
+    int first_site = -1;
+    void* host_stage = nullptr;     // for fav_classify_host
+    // profiling
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    fav_profile prof{};
+};
+
+namespace {
+
+using namespace fav;
+
+int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+// ------------------------------------------------------------------ launchers
+struct Prof {
+    fav_handle* h;
+    hipStream_t s;
+    int idx = -1;
+    Prof(fav_handle* h_, hipStream_t s_, int cls, double flops, double bytes) : h(h_), s(s_) {
+        if (!h || !h->profiling) return;
+        if (h->ev_used == h->ev_pool.size()) {
+            fav_handle::Ev e;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+            h->ev_pool.push_back(e);
+        }
+        idx = (int)h->ev_used++;
+        h->ev_pool[idx].cls = cls;
+        h->prof.flops[cls] += flops;
+        h->prof.bytes[cls] += bytes;
+        h->prof.launches[cls] += 1;
+        (void)hipEventRecord(h->ev_pool[idx].a, s);
+    }
+    ~Prof() {
+        if (idx >= 0) (void)hipEventRecord(h->ev_pool[idx].b, s);
+    }
+};
+
+DropParams make_drop(const fav_dropout_desc* d) {
+    DropParams p;
+    if (!d || d->site < 0) {
+        p.site = -1; p.thr = 0; p.scale = 1.f; p.seed_lo = p.seed_hi = 0; p.v0 = 0; p.n_img = 1; p.first_index = 0;
+        return p;
+    }
+    p.site = d->site;
+    p.thr = d->threshold;
+    p.scale = d->scale;
+    p.seed_lo = (uint32_t)(d->seed & 0xFFFFFFFFull);
+    p.seed_hi = (uint32_t)(d->seed >> 32);
+    p.v0 = d->v0;
+    p.n_img = d->n_img > 0 ? d->n_img : 1;
+    p.first_index = d->first_image_index;
+    return p;
+}
+
+const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int ldy, hipStream_t s) {
+    if (d.Cin % 64 != 0) return "conv: Cin must be a multiple of 64";
+    if (cout_pad % 64 != 0) return "conv: padded Cout must be a multiple of 64";
+    ConvParams p;
+    p.x = (const uint16_t*)d.x; p.w = (const uint16_t*)d.w; p.bias = d.bias; p.res = (const uint16_t*)d.res; p.y = d.y;
+    p.H = d.H; p.W = d.W; p.Cin = d.Cin;
+    p.Ho = conv_out(d.H, d.kh, d.stride, d.pad);
+    p.Wo = conv_out(d.W, d.kw, d.stride, d.pad);
+    p.HWo = p.Ho * p.Wo;
+    p.Cout = d.Cout; p.ldy = ldy;
+    p.kw = d.kw; p.stride = d.stride; p.pad = d.pad;
+    const long long M = (long long)d.n_frames * p.HWo;
+    if (M <= 0 || M > 0x7fffffffLL) return "conv: row count out of range";
+    p.M = (int)M;
+    p.K = d.kh * d.kw * d.Cin; p.nk = p.K / 64;
+    p.relu = d.relu; p.out_f32 = d.out_f32;
+    p.drop = make_drop(&d.drop);
+    if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
+    const int BM = 128;
+    const int BN = (cout_pad % 128 == 0) ? 128 : 64;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = cout_pad / BN;
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    if (tiles > 0x7fffffffLL) return "conv: too many tiles";
+    const double flops = 2.0 * (double)M * d.Cout * p.K;
+    const double bytes = 2.0 * ((double)d.n_frames * d.H * d.W * d.Cin + (double)M * d.Cout * (d.res ? 2 : 1) * (d.out_f32 ? 2 : 1)
+                                + (double)d.Cout * p.K);
+    Prof pr(h, s, FAV_K_CONV, flops, bytes);
+    dim3 grid((unsigned)tiles), block(256);
+    if (d.math_mode == FAV_MATH_BF16) {
+        if (BN == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 0>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 0>), grid, block, 0, s, p);
+    } else {
+        if (BN == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 1>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 1>), grid, block, 0, s, p);
+    }
+    return nullptr;
+}
+
+unsigned grid_for(long long work_items) {
+    long long g = (work_items + 255) / 256;
+    return (unsigned)std::max<long long>(1, std::min<long long>(g, 256 * 16));
+}
+
+void launch_stem(fav_handle* h, const void* images, int layout, int n, int H, int W, int kh, int kw, int stride, int pad,
+                 int kpad, const float* mean, const float* istd, void* out, hipStream_t s) {
+    const int Ho = conv_out(H, kh, stride, pad), Wo = conv_out(W, kw, stride, pad);
+    const long long total = (long long)n * Ho * Wo * (kpad / 8);
+    Prof pr(h, s, FAV_K_STEM, 0.0, (double)n * H * W * 3 * (layout == 0 ? 1 : 4) + (double)total * 16);
+    if (layout == FAV_LAYOUT_NHWC_U8)
+        hipLaunchKernelGGL((stem_im2col_kernel<0>), dim3(grid_for(total)), dim3(256), 0, s, images, (uint4*)out, n, H, W,
+                           Ho, Wo, kh, kw, stride, pad, kpad, mean[0], mean[1], mean[2], istd[0], istd[1], istd[2]);
+    else
+        hipLaunchKernelGGL((stem_im2col_kernel<1>), dim3(grid_for(total)), dim3(256), 0, s, images, (uint4*)out, n, H, W,
+                           Ho, Wo, kh, kw, stride, pad, kpad, mean[0], mean[1], mean[2], istd[0], istd[1], istd[2]);
+}
+
+void launch_maxpool(fav_handle* h, const void* x, void* y, int n, int H, int W, int C, hipStream_t s) {
+    const int Ho = conv_out(H, 3, 2, 1), Wo = conv_out(W, 3, 2, 1);
+    const long long total = (long long)n * Ho * Wo * (C / 8);
+    Prof pr(h, s, FAV_K_MAXPOOL, 0.0, 2.0 * ((double)n * H * W * C + (double)n * Ho * Wo * C));
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)y, n, H, W,
+                       C, Ho, Wo);
+}
+
+void launch_avgpool(fav_handle* h, const void* x, void* y, int n, int HW, int C, const DropParams& dp, hipStream_t s) {
+    const long long total = (long long)n * (C / 8);
+    Prof pr(h, s, FAV_K_AVGPOOL, 0.0, 2.0 * ((double)n * HW * C + (double)n * C));
+    const float inv = 1.0f / (float)HW;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)y, n, HW, C, inv,
+                       dp);
+}
+
+void launch_entry_dropout(fav_handle* h, const void* x, void* out, long long elems, int n_out, const DropParams& dp,
+                          hipStream_t s) {
+    const long long total = (elems / 8) * n_out;
+    Prof pr(h, s, FAV_K_DROPOUT, 0.0, 4.0 * (double)elems * n_out);
+    hipLaunchKernelGGL(entry_dropout_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)out,
+                       elems / 8, n_out, dp);
+}
+
+const char* launch_head(fav_handle* h, const float* logits, int T, int n, int C, int ld, float temperature, int kind,
+                        float tau, int* labels, float* conf, uint8_t* fail, float* score, hipStream_t s) {
+    if (C > 1024 || C < 1) return "head: num_classes must be in [1, 1024]";
+    if (ld % 4 != 0 || ld < C) return "head: bad row stride";
+    const float inv_temp = 1.0f / temperature;
+    const float inv_lnC = C > 1 ? (float)(1.0 / std::log((double)C)) : 0.f;
+    Prof pr(h, s, FAV_K_HEAD, 0.0, 4.0 * (double)T * n * C + 8.0 * n);
+    if (C <= 256)
+        hipLaunchKernelGGL((head_kernel<1>), dim3(n), dim3(256), 0, s, logits, T, n, C, ld, inv_temp, kind, tau, inv_lnC,
+                           labels, conf, fail, score);
+    else
+        hipLaunchKernelGGL((head_kernel<4>), dim3(n), dim3(256), 0, s, logits, T, n, C, ld, inv_temp, kind, tau, inv_lnC,
+                           labels, conf, fail, score);
+    return nullptr;
+}
+
+// ------------------------------------------------------------------ graph build
+fav_status build_graph(fav_handle* h) {
+    const fav_config& c = h->cfg;
+    const ArchDef& A = kArch[c.arch];
+    h->layers.clear();
+    h->ops.clear();
+    auto add_layer = [&](int cout, int cin, int kh, int kw, int stride, int pad) {
+        Layer L;
+        L.cout = cout; L.cin = cin; L.kh = kh; L.kw = kw; L.stride = stride; L.pad = pad;
+        L.cout_pad = (cout + 63) / 64 * 64;
+        L.k = kh * kw * cin;
+        h->layers.push_back(L);
+        return (int)h->layers.size() - 1;
+    };
+    int H = c.in_h, W = c.in_w;
+    // stem: im2col (normalise fused) + dense GEMM over the padded patch matrix
+    int sk = A.imagenet_stem ? 7 : 3, ss = A.imagenet_stem ? 2 : 1, sp = A.imagenet_stem ? 3 : 1;
+    int li = add_layer(64, 3, sk, sk, ss, sp);
+    {
+        Layer& L = h->layers[li];
+        L.k = (sk * sk * 3 + 63) / 64 * 64;  // device K is the padded patch length
+    }
+    int Ho = conv_out(H, sk, ss, sp), Wo = conv_out(W, sk, ss, sp);
+    if (Ho < 1 || Wo < 1) { h->err = "input too small"; return FAV_ERR_INVALID_ARG; }
+    int cur = 0;  // rotating buffer holding the current activation
+    auto other = [&](std::initializer_list<int> used) {
+        for (int i = 0; i < 5; ++i) {
+            bool u = false;
+            for (int x : used) u |= (x == i);
+            if (!u) return i;
+        }
+        return -1;
+    };
+    {
+        Op o; o.kind = OP_STEM_IM2COL; o.layer = li; o.in = B_INPUT; o.out = B_A1;
+        o.H = H; o.W = W; o.C = 3; o.Ho = Ho; o.Wo = Wo; o.Co = h->layers[li].k;
+        o.in_elems = (long long)H * W * 3; o.out_elems = (long long)Ho * Wo * o.Co;
+        h->ops.push_back(o);
+        Op g; g.kind = OP_CONV; g.layer = li; g.in = B_A1; g.out = cur; g.relu = 1;
+        g.H = Ho; g.W = Wo; g.C = h->layers[li].k; g.Ho = Ho; g.Wo = Wo; g.Co = 64;
+        g.in_elems = o.out_elems; g.out_elems = (long long)Ho * Wo * 64;
+        h->ops.push_back(g);
+    }
+    H = Ho; W = Wo;
+    int C = 64;
+    if (A.imagenet_stem) {
+        Op o; o.kind = OP_MAXPOOL; o.in = cur; o.out = other({cur});
+        o.H = H; o.W = W; o.C = C; o.Ho = conv_out(H, 3, 2, 1); o.Wo = conv_out(W, 3, 2, 1); o.Co = C;
+        o.in_elems = (long long)H * W * C; o.out_elems = (long long)o.Ho * o.Wo * C;
+        h->ops.push_back(o);
+        cur = o.out; H = o.Ho; W = o.Wo;
+    }
+    std::vector<int> block_last_op;
+    const int exp = A.bottleneck ? 4 : 1;
+    int inpl = 64, bidx = 0;
+    for (int st = 0; st < 4; ++st) {
+        for (int bi = 0; bi < A.depths[st]; ++bi, ++bidx) {
+            const int pl = A.planes[st];
+            const int s = (bi == 0 && st > 0) ? 2 : 1;
+            const bool ds = (bi == 0) && (s != 1 || inpl != pl * exp);
+            const int xin = cur;
+            int t1 = other({xin}), t2 = other({xin, t1});
+            auto conv_op = [&](int layer, int in, int out, int res, int relu, int Hi, int Wi) {
+                const Layer& L = h->layers[layer];
+                Op o; o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.res = res; o.relu = relu;
+                o.H = Hi; o.W = Wi; o.C = L.cin;
+                o.Ho = conv_out(Hi, L.kh, L.stride, L.pad); o.Wo = conv_out(Wi, L.kw, L.stride, L.pad); o.Co = L.cout;
+                o.in_elems = (long long)Hi * Wi * L.cin; o.out_elems = (long long)o.Ho * o.Wo * L.cout;
+                h->ops.push_back(o);
+                return o;
+            };
+            int Hn, Wn;
+            if (A.bottleneck) {
+                int l1 = add_layer(pl, inpl, 1, 1, 1, 0), l2 = add_layer(pl, pl, 3, 3, s, 1), l3 = add_layer(pl * 4, pl, 1, 1, 1, 0);
+                conv_op(l1, xin, t1, B_NONE, 1, H, W);
+                Op o2 = conv_op(l2, t1, t2, B_NONE, 1, H, W);
+                Hn = o2.Ho; Wn = o2.Wo;
+                int idn = xin;
+                int ld = -1;
+                if (ds) ld = add_layer(pl * exp, inpl, 1, 1, s, 0);
+                // blob order is conv1, conv2, conv3, downsample; launch order: downsample before conv3
+                if (ds) { idn = other({xin, t1, t2}); conv_op(ld, xin, idn, B_NONE, 0, H, W); }
+                int yout = ds ? other({xin, t1, t2, idn}) : t1;  // t1 is dead after conv2
+                conv_op(l3, t2, yout, idn, 1, Hn, Wn);
+                cur = yout;
+            } else {
+                int l1 = add_layer(pl, inpl, 3, 3, s, 1), l2 = add_layer(pl, pl, 3, 3, 1, 1);
+                Op o1 = conv_op(l1, xin, t1, B_NONE, 1, H, W);
+                Hn = o1.Ho; Wn = o1.Wo;
+                int idn = xin, ld = -1;
+                if (ds) ld = add_layer(pl * exp, inpl, 1, 1, s, 0);
+                if (ds) { idn = t2; conv_op(ld, xin, idn, B_NONE, 0, H, W); }
+                int yout = other({xin, t1, idn});
+                conv_op(l2, t1, yout, idn, 1, Hn, Wn);
+                cur = yout;
+            }
+            block_last_op.push_back((int)h->ops.size() - 1);
+            H = Hn; W = Wn; inpl = pl * exp; C = inpl;
+        }
+    }
+    h->nblocks = bidx;
+    {
+        Op o; o.kind = OP_AVGPOOL; o.in = cur; o.out = other({cur});
+        o.H = H; o.W = W; o.C = C; o.Ho = 1; o.Wo = 1; o.Co = C;
+        o.in_elems = (long long)H * W * C; o.out_elems = C;
+        h->ops.push_back(o);
+        cur = o.out;
+    }
+    const int pool_op = (int)h->ops.size() - 1;
+    int lfc = add_layer(c.num_classes, C, 1, 1, 1, 0);
+    h->cpad = h->layers[lfc].cout_pad;
+    {
+        Op o; o.kind = OP_CONV; o.layer = lfc; o.in = cur; o.out = other({cur}); o.out_f32 = 1;
+        o.H = 1; o.W = 1; o.C = C; o.Ho = 1; o.Wo = 1; o.Co = c.num_classes;
+        o.in_elems = C; o.out_elems = h->cpad;
+        h->ops.push_back(o);
+    }
+
+    // ---- dropout sites and prefix / suffix split -----------------------------
+    const uint32_t valid_mask = (h->nblocks + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (h->nblocks + 1)) - 1);
+    if (c.site_mask & ~valid_mask) { h->err = "site_mask has bits beyond the pooled-feature site"; return FAV_ERR_INVALID_ARG; }
+    const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 65536.0);
+    const bool mc = c.site_mask != 0 && thr > 0;
+    h->T_eff = mc ? c.n_samples : 1;
+    h->first_site = -1;
+    int split = (int)h->ops.size();  // ops [0, split) are the prefix
+    if (mc) {
+        for (int s = 0; s <= h->nblocks; ++s)
+            if (c.site_mask >> s & 1) { h->first_site = s; break; }
+        const int first_op = h->first_site < h->nblocks ? block_last_op[h->first_site] : pool_op;
+        split = first_op + 1;
+        for (int s = h->first_site + 1; s <= h->nblocks; ++s)
+            if (c.site_mask >> s & 1) h->ops[s < h->nblocks ? block_last_op[s] : pool_op].site = s;
+    }
+    // op index where the low-resolution group starts
+    int regroup = c.regroup_block;
+    if (regroup < 0) regroup = A.bottleneck ? A.depths[0] + A.depths[1] : A.depths[0] + A.depths[1];
+    regroup = std::min(regroup, h->nblocks);
+    const int regroup_op = regroup == 0 ? (A.imagenet_stem ? 3 : 2)
+                                        : (regroup >= h->nblocks ? pool_op : block_last_op[regroup - 1] + 1);
+
+    // ---- phases ---------------------------------------------------------------
+    h->phases.clear();
+    int regroup_now = regroup_op;  // op index of the low-resolution group in the CURRENT op list
+    auto add_phase = [&](int b, int e, bool suffix) {
+        if (b >= e) return;
+        Phase p; p.op_begin = b; p.op_end = e; p.suffix = suffix;
+        p.low_res = b >= regroup_now;
+        p.in_elems = h->ops[b].in_elems;
+        p.out_elems = h->ops[e - 1].out_elems;
+        p.out_bytes_per_elem = h->ops[e - 1].out_f32 ? 4 : 2;
+        p.chunk = 0;
+        h->phases.push_back(p);
+    };
+    auto add_range = [&](int b, int e, bool suffix) {
+        if (b < regroup_op && regroup_op < e) { add_phase(b, regroup_op, suffix); add_phase(regroup_op, e, suffix); }
+        else add_phase(b, e, suffix);
+    };
+    add_range(0, split, false);
+    if (mc) {
+        // the suffix starts with the entry dropout of the cached prefix output
+        Op ed; ed.kind = OP_ENTRY_DROPOUT; ed.in = B_PHASE_IN; ed.site = h->first_site;
+        ed.in_elems = ed.out_elems = h->ops[split - 1].out_elems;
+        ed.out = 0;  // patched below
+        // insert before ops[split]; the op list after `split` reads its input from
+        // whatever buffer the prefix's last op wrote, so write the dropout there.
+        ed.out = h->ops[split - 1].out;
+        h->ops.insert(h->ops.begin() + split, ed);
+        regroup_now = regroup_op >= split ? regroup_op + 1 : regroup_op;
+        const int nops = (int)h->ops.size();
+        // split the suffix only if at least one real op lies on each side
+        if (split + 1 < regroup_now && regroup_now < nops) { add_phase(split, regroup_now, true); add_phase(regroup_now, nops, true); }
+        else add_phase(split, nops, true);
+    }
+    // mark phase boundaries in the ops' buffers
+    for (size_t i = 0; i < h->phases.size(); ++i) {
+        Phase& p = h->phases[i];
+        Op& first = h->ops[p.op_begin];
+        if (first.kind != OP_STEM_IM2COL) {
+            // consumers of the phase input: every op in the phase reading the buffer the
+            // previous phase's last op wrote, until that rotating buffer is overwritten
+            const int src = (first.kind == OP_ENTRY_DROPOUT) ? B_PHASE_IN : first.in;
+            if (first.kind != OP_ENTRY_DROPOUT) {
+                for (int k = p.op_begin; k < p.op_end; ++k) {
+                    Op& o = h->ops[k];
+                    if (o.in == src) o.in = B_PHASE_IN;
+                    if (o.res == src) o.res = B_PHASE_IN;
+                    if (o.out == src) break;
+                }
+            }
+        }
+        h->ops[p.op_end - 1].out = B_PHASE_OUT;
+    }
+    return FAV_OK;
+}
+
+// ------------------------------------------------------------------ memory plan
+fav_status plan_memory(fav_handle* h) {
+    const fav_config& c = h->cfg;
+    const long long nv_max = (long long)c.max_batch * h->T_eff;
+    // chunk sizes
+    long long max_elems = 1, max_a1 = 1;
+    for (const Op& o : h->ops) {
+        if (o.out == B_A1) max_a1 = std::max(max_a1, o.out_elems);
+        else if (o.out >= 0) max_elems = std::max(max_elems, o.out_elems);
+    }
+    for (size_t i = 0; i < h->phases.size(); ++i) {
+        Phase& p = h->phases[i];
+        long long pe = 1;
+        for (int k = p.op_begin; k < p.op_end; ++k) {
+            const Op& o = h->ops[k];
+            pe = std::max(pe, o.out == B_A1 ? o.out_elems / 2 : o.out_elems);
+        }
+        // aim at ~40 MB per activation tensor so a block's live tensors sit in the 256 MiB L3,
+        // but never fewer rows than fill the CUs on the small late layers
+        const long long target = 40ll << 20;
+        long long auto_chunk = std::max<long long>(1, target / (pe * 2));
+        const int want = p.low_res ? c.chunk_b : c.chunk_a;
+        long long chunk = want > 0 ? want : auto_chunk;
+        const long long dom = p.suffix ? nv_max : c.max_batch;
+        p.chunk = (int)std::max<long long>(1, std::min(chunk, dom));
+    }
+    int max_chunk = 1;
+    for (const Phase& p : h->phases) max_chunk = std::max(max_chunk, p.chunk);
+    // rotating buffers sized for the largest (chunk x tensor) in any phase
+    size_t act_bytes = 0, a1_bytes = 0;
+    for (const Phase& p : h->phases)
+        for (int k = p.op_begin; k < p.op_end; ++k) {
+            const Op& o = h->ops[k];
+            const size_t b = (size_t)o.out_elems * (o.out_f32 ? 4 : 2) * p.chunk;
+            if (o.out == B_A1) a1_bytes = std::max(a1_bytes, b);
+            else if (o.out >= 0) act_bytes = std::max(act_bytes, b);
+        }
+    act_bytes = (act_bytes + 255) / 256 * 256 + 256;
+    a1_bytes = (a1_bytes + 255) / 256 * 256 + 256;
+    for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&h->act[i], act_bytes));
+    h->act_bytes = act_bytes;
+    HIP_TRY(h, hipMalloc(&h->a1, a1_bytes));
+    h->a1_bytes = a1_bytes;
+    h->phase_out.assign(h->phases.size(), nullptr);
+    for (size_t i = 0; i + 1 < h->phases.size(); ++i) {
+        const Phase& p = h->phases[i];
+        const long long dom = p.suffix ? nv_max : c.max_batch;
+        HIP_TRY(h, hipMalloc(&h->phase_out[i], (size_t)dom * p.out_elems * p.out_bytes_per_elem + 256));
+    }
+    HIP_TRY(h, hipMalloc((void**)&h->logits, (size_t)nv_max * h->cpad * 4 + 256));
+    h->phase_out.back() = h->logits;
+    return FAV_OK;
+}
+
+// ------------------------------------------------------------------ execution
+fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, int n, long long first_index,
+                     hipStream_t s) {
+    const fav_config& c = h->cfg;
+    const Phase& p = h->phases[pi];
+    const long long dom = p.suffix ? (long long)n * h->T_eff : n;
+    const char* pin_base = pi == 0 ? (const char*)images : (const char*)h->phase_out[pi - 1];
+    const int in_bpe = pi == 0 ? (layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4) : h->phases[pi - 1].out_bytes_per_elem;
+    // a suffix phase that follows the prefix reads frame (v % n); later phases read virtual frame v
+    const bool in_is_virtual = pi > 0 && h->phases[pi - 1].suffix;
+    char* pout_base = (char*)h->phase_out[pi];
+    const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 65536.0);
+    const float scale = thr > 0 ? (float)(1.0 / (1.0 - thr / 65536.0)) : 1.0f;
+    float istd[3] = {1.0f / c.stdev[0], 1.0f / c.stdev[1], 1.0f / c.stdev[2]};
+
+    for (long long v0 = 0; v0 < dom; v0 += p.chunk) {
+        const int cn = (int)std::min<long long>(p.chunk, dom - v0);
+        auto buf = [&](int id, bool is_out, const Op& o) -> void* {
+            switch (id) {
+                case B_INPUT: return (void*)(pin_base + (size_t)v0 * o.in_elems * in_bpe);
+                case B_PHASE_IN:
+                    if (!in_is_virtual && p.suffix) return (void*)pin_base;  // entry dropout indexes v % n itself
+                    return (void*)(pin_base + (size_t)v0 * p.in_elems * in_bpe);
+                case B_PHASE_OUT: return (void*)(pout_base + (size_t)v0 * p.out_elems * p.out_bytes_per_elem);
+                case B_A1: return h->a1;
+                case B_NONE: return nullptr;
+                default: return h->act[id];
+            }
+        };
+        for (int k = p.op_begin; k < p.op_end; ++k) {
+            const Op& o = h->ops[k];
+            fav_dropout_desc dd;
+            dd.site = o.site; dd.threshold = thr; dd.scale = scale; dd.seed = c.seed;
+            dd.v0 = p.suffix ? v0 : 0; dd.n_img = n; dd.first_image_index = first_index;
+            switch (o.kind) {
+                case OP_STEM_IM2COL: {
+                    const Layer& L = h->layers[o.layer];
+                    launch_stem(h, buf(o.in, false, o), layout, cn, o.H, o.W, L.kh, L.kw, L.stride, L.pad, L.k, c.mean,
+                                istd, buf(o.out, true, o), s);
+                    break;
+                }
+                case OP_CONV: {
+                    const Layer& L = h->layers[o.layer];
+                    fav_conv_desc d;
+                    d.x = buf(o.in, false, o); d.w = L.w; d.bias = L.b; d.res = buf(o.res, false, o); d.y = buf(o.out, true, o);
+                    d.n_frames = cn; d.H = o.H; d.W = o.W; d.Cin = o.C; d.Cout = L.cout;
+                    // the stem GEMM runs as a 1x1 conv over the im2col matrix
+                    const bool stem = (o.in == B_A1);
+                    d.kh = stem ? 1 : L.kh; d.kw = stem ? 1 : L.kw; d.stride = stem ? 1 : L.stride; d.pad = stem ? 0 : L.pad;
+                    d.relu = o.relu; d.out_f32 = o.out_f32; d.math_mode = c.math_mode;
+                    d.drop = dd;
+                    const int ldy = o.out_f32 ? L.cout_pad : L.cout;
+                    if (const char* e = launch_conv(h, d, L.cout_pad, ldy, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
+                    break;
+                }
+                case OP_MAXPOOL:
+                    launch_maxpool(h, buf(o.in, false, o), buf(o.out, true, o), cn, o.H, o.W, o.C, s);
+                    break;
+                case OP_AVGPOOL: {
+                    DropParams dp = make_drop(&dd);
+                    launch_avgpool(h, buf(o.in, false, o), buf(o.out, true, o), cn, o.H * o.W, o.C, dp, s);
+                    break;
+                }
+                case OP_ENTRY_DROPOUT: {
+                    DropParams dp = make_drop(&dd);
+                    launch_entry_dropout(h, pin_base, buf(o.out, true, o), o.in_elems, cn, dp, s);
+                    break;
+                }
+            }
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return FAV_OK;
+}
+
+void free_all(fav_handle* h) {
+    for (auto& L : h->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); L.w = nullptr; L.b = nullptr; }
+    for (int i = 0; i < 5; ++i) if (h->act[i]) (void)hipFree(h->act[i]);
+    if (h->a1) (void)hipFree(h->a1);
+    for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
+    if (h->logits) (void)hipFree(h->logits);
+    if (h->host_stage) (void)hipFree(h->host_stage);
+    for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+int32_t fav_abi_version(void) { return FAV_ABI_VERSION; }
+
+void fav_default_config(fav_config* c, int32_t arch) {
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->struct_size = sizeof *c;
+    c->device = 0;
+    c->arch = arch;
+    c->num_classes = arch == FAV_ARCH_RESNET50 ? 1000 : 10;
+    c->in_h = c->in_w = arch == FAV_ARCH_RESNET50 ? 224 : 32;
+    c->max_batch = 256;
+    c->mean[0] = 0.485f; c->mean[1] = 0.456f; c->mean[2] = 0.406f;
+    c->stdev[0] = 0.229f; c->stdev[1] = 0.224f; c->stdev[2] = 0.225f;
+    c->n_samples = 1;
+    c->site_mask = 0;
+    c->dropout_p = 0.f;
+    c->seed = 0;
+    c->temperature = 1.f;
+    c->conf_kind = FAV_CONF_MAX_SOFTMAX;
+    c->tau = 0.5f;
+    c->math_mode = FAV_MATH_BF16;
+    c->chunk_a = 0; c->chunk_b = 0; c->regroup_block = -1;
+}
+
+const char* fav_last_error(const fav_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+fav_status fav_create(const fav_config* cfg, fav_handle** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out) { g_create_error = "fav_create: null argument"; return FAV_ERR_INVALID_ARG; }
+    if (cfg->struct_size != sizeof(fav_config)) { g_create_error = "fav_create: fav_config.struct_size mismatch"; return FAV_ERR_INVALID_ARG; }
+    if (cfg->arch < 0 || cfg->arch > 1) { g_create_error = "fav_create: unknown arch"; return FAV_ERR_UNSUPPORTED; }
+    if (cfg->num_classes < 1 || cfg->num_classes > 1024 || cfg->max_batch < 1 || cfg->in_h < 8 || cfg->in_w < 8 ||
+        cfg->n_samples < 1 || cfg->n_samples > 4096 || !(cfg->temperature > 0.f) || cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f ||
+        !(cfg->stdev[0] > 0.f && cfg->stdev[1] > 0.f && cfg->stdev[2] > 0.f) || cfg->math_mode < 0 || cfg->math_mode > 1 ||
+        cfg->conf_kind < 0 || cfg->conf_kind > 1) {
+        g_create_error = "fav_create: config value out of range";
+        return FAV_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        (void)hipGetLastError();
+        g_create_error = fmt("fav_create: no usable HIP device (count=%d, requested=%d); this path has no CPU fallback", ndev, cfg->device);
+        return FAV_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = fmt("fav_create: device %d is '%s', kernels are built for gfx950 only", cfg->device, prop.gcnArchName);
+        return FAV_ERR_NO_DEVICE;
+    }
+    fav_handle* h = new fav_handle();
+    h->cfg = *cfg;
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; delete h; return FAV_ERR_HIP; }
+    fav_status st = build_graph(h);
+    if (st == FAV_OK) st = plan_memory(h);
+    if (st != FAV_OK) { g_create_error = h->err; free_all(h); delete h; return st; }
+    *out = h;
+    return FAV_OK;
+}
+
+void fav_destroy(fav_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    free_all(h);
+    delete h;
+}
+
+fav_status fav_load_weights(fav_handle* h, const void* blob, size_t size) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    if (!blob || size < 32) { h->err = "fav_load_weights: blob too small"; return FAV_ERR_BAD_BLOB; }
+    const uint8_t* p = (const uint8_t*)blob;
+    uint32_t hdr[8];
+    memcpy(hdr, p, 32);
+    if (hdr[0] != 0x57564146u || hdr[1] != 1u) { h->err = "fav_load_weights: not a FAVW v1 blob"; return FAV_ERR_BAD_BLOB; }
+    if ((int)hdr[2] != h->cfg.arch || (int)hdr[3] != h->cfg.num_classes || hdr[4] != h->layers.size()) {
+        h->err = fmt("fav_load_weights: blob is arch %u / %u classes / %u layers, handle expects %d / %d / %zu", hdr[2], hdr[3],
+                     hdr[4], h->cfg.arch, h->cfg.num_classes, h->layers.size());
+        return FAV_ERR_BAD_BLOB;
+    }
+    if (size < 32 + 48 * (size_t)hdr[4]) { h->err = "fav_load_weights: truncated layer table"; return FAV_ERR_BAD_BLOB; }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    std::vector<uint16_t> wtmp;
+    std::vector<float> btmp;
+    for (size_t i = 0; i < h->layers.size(); ++i) {
+        Layer& L = h->layers[i];
+        uint32_t t[8];
+        uint64_t off[2];
+        memcpy(t, p + 32 + 48 * i, 32);
+        memcpy(off, p + 32 + 48 * i + 32, 16);
+        if ((int)t[0] != L.cout || (int)t[1] != L.cin || (int)t[2] != L.kh || (int)t[3] != L.kw || (int)t[4] != L.stride ||
+            (int)t[5] != L.pad) {
+            h->err = fmt("fav_load_weights: layer %zu shape mismatch", i);
+            return FAV_ERR_BAD_BLOB;
+        }
+        const size_t kreal = (size_t)L.kh * L.kw * L.cin;
+        const size_t wbytes = (size_t)L.cout * kreal * 2, bbytes = (size_t)L.cout * 4;
+        if (off[0] + wbytes > size || off[1] + bbytes > size) { h->err = fmt("fav_load_weights: layer %zu data out of range", i); return FAV_ERR_BAD_BLOB; }
+        // device layout: [cout_pad][L.k] bf16, zero padded in both dimensions
+        wtmp.assign((size_t)L.cout_pad * L.k, 0);
+        const uint16_t* src = (const uint16_t*)(p + off[0]);
+        for (int n = 0; n < L.cout; ++n) memcpy(&wtmp[(size_t)n * L.k], src + (size_t)n * kreal, kreal * 2);
+        btmp.assign(L.cout_pad, 0.f);
+        memcpy(btmp.data(), p + off[1], bbytes);
+        if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, wtmp.size() * 2));
+        if (!L.b) HIP_TRY(h, hipMalloc((void**)&L.b, btmp.size() * 4));
+        HIP_TRY(h, hipMemcpy(L.w, wtmp.data(), wtmp.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(L.b, btmp.data(), btmp.size() * 4, hipMemcpyHostToDevice));
+    }
+    h->weights_loaded = true;
+    return FAV_OK;
+}
+
+fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
+                           int32_t* labels, float* conf, uint8_t* fail, float* score, void* stream) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    if (!h->weights_loaded) { h->err = "fav_classify: no weights loaded"; return FAV_ERR_NO_WEIGHTS; }
+    if (!images || !labels || !conf) { h->err = "fav_classify: null buffer"; return FAV_ERR_INVALID_ARG; }
+    if (n < 1 || n > h->cfg.max_batch) { h->err = fmt("fav_classify: n=%d outside [1, max_batch=%d]", n, h->cfg.max_batch); return FAV_ERR_INVALID_ARG; }
+    if (layout != FAV_LAYOUT_NHWC_U8 && layout != FAV_LAYOUT_NHWC_F32) { h->err = "fav_classify: unknown layout"; return FAV_ERR_INVALID_ARG; }
+    if (first_index < 0 || first_index + n > 0xFFFFFFFFll) { h->err = "fav_classify: first_image_index out of range"; return FAV_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->ev_used = h->profiling ? h->ev_used : 0;
+    for (size_t pi = 0; pi < h->phases.size(); ++pi) {
+        fav_status st = run_phase(h, pi, images, layout, n, first_index, s);
+        if (st != FAV_OK) return st;
+    }
+    if (const char* e = launch_head(h, h->logits, h->T_eff, n, h->cfg.num_classes, h->cpad, h->cfg.temperature,
+                                    h->cfg.conf_kind, h->cfg.tau, labels, conf, fail, score, s)) {
+        h->err = e;
+        return FAV_ERR_INVALID_ARG;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->last_T = h->T_eff;
+    h->last_n = n;
+    return FAV_OK;
+}
+
+fav_status fav_classify(fav_handle* h, const void* images, int32_t n, int32_t layout, int32_t* labels, float* conf,
+                        void* stream) {
+    return fav_classify_ex(h, images, n, layout, 0, labels, conf, nullptr, nullptr, stream);
+}
+
+fav_status fav_classify_host(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
+                             int32_t* labels, float* conf, uint8_t* fail, float* score) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    if (!images || !labels || !conf || n < 1 || n > h->cfg.max_batch) { h->err = "fav_classify_host: bad argument"; return FAV_ERR_INVALID_ARG; }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t bpe = layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4;
+    const size_t img_bytes = (size_t)h->cfg.max_batch * h->cfg.in_h * h->cfg.in_w * 3 * 4;
+    const size_t res_off = (img_bytes + 255) / 256 * 256;
+    if (!h->host_stage) HIP_TRY(h, hipMalloc(&h->host_stage, res_off + (size_t)h->cfg.max_batch * 16 + 256));
+    char* base = (char*)h->host_stage;
+    int32_t* dl = (int32_t*)(base + res_off);
+    float* dc = (float*)(dl + h->cfg.max_batch);
+    float* ds = dc + h->cfg.max_batch;
+    uint8_t* df = (uint8_t*)(ds + h->cfg.max_batch);
+    HIP_TRY(h, hipMemcpy(base, images, (size_t)n * h->cfg.in_h * h->cfg.in_w * 3 * bpe, hipMemcpyHostToDevice));
+    fav_status st = fav_classify_ex(h, base, n, layout, first_index, dl, dc, df, ds, nullptr);
+    if (st != FAV_OK) return st;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(labels, dl, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(conf, dc, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (score) HIP_TRY(h, hipMemcpy(score, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (fail) HIP_TRY(h, hipMemcpy(fail, df, (size_t)n, hipMemcpyDeviceToHost));
+    return FAV_OK;
+}
+
+fav_status fav_get_logits(fav_handle* h, float* out, int32_t* t_out, int32_t* n_out, void* stream) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    if (h->last_n == 0) { h->err = "fav_get_logits: no classify call yet"; return FAV_ERR_INVALID_ARG; }
+    if (t_out) *t_out = h->last_T;
+    if (n_out) *n_out = h->last_n;
+    if (out) {
+        HIP_TRY(h, hipMemcpy2DAsync(out, (size_t)h->cfg.num_classes * 4, h->logits, (size_t)h->cpad * 4,
+                                    (size_t)h->cfg.num_classes * 4, (size_t)h->last_T * h->last_n,
+                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return FAV_OK;
+}
+
+fav_status fav_set_profiling(fav_handle* h, int32_t enable) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    h->profiling = enable != 0;
+    h->ev_used = 0;
+    memset(&h->prof, 0, sizeof h->prof);
+    return FAV_OK;
+}
+
+fav_status fav_get_profile(fav_handle* h, fav_profile* out, int32_t reset) {
+    if (!h || !out) return FAV_ERR_INVALID_ARG;
+    HIP_TRY(h, hipDeviceSynchronize());
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) == hipSuccess) h->prof.ms[h->ev_pool[i].cls] += ms;
+    }
+    h->ev_used = 0;
+    *out = h->prof;
+    if (reset) memset(&h->prof, 0, sizeof h->prof);
+    return FAV_OK;
+}
+
+// ---- operator level --------------------------------------------------------
+static fav_status op_done(const char* e) {
+    if (e) { g_create_error = e; return FAV_ERR_INVALID_ARG; }
+    if (hipGetLastError() != hipSuccess) { g_create_error = "kernel launch failed"; return FAV_ERR_HIP; }
+    return FAV_OK;
+}
+
+fav_status fav_op_conv2d(const fav_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->bias || !d->y) return op_done("fav_op_conv2d: null pointer");
+    if (d->Cout % 64 != 0) return op_done("fav_op_conv2d: Cout must be a multiple of 64");
+    return op_done(launch_conv(nullptr, *d, d->Cout, d->Cout, (hipStream_t)stream));
+}
+
+fav_status fav_op_stem_im2col(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W, int32_t kh, int32_t kw,
+                              int32_t stride, int32_t pad, int32_t kpad, const float* mean3, const float* inv_std3,
+                              void* out, void* stream) {
+    if (!images || !out || !mean3 || !inv_std3 || kpad % 64 != 0 || kpad < kh * kw * 3) return op_done("fav_op_stem_im2col: bad argument");
+    launch_stem(nullptr, images, layout, n, H, W, kh, kw, stride, pad, kpad, mean3, inv_std3, out, (hipStream_t)stream);
+    return op_done(nullptr);
+}
+
+fav_status fav_op_maxpool3x3s2(const void* x, void* y, int32_t n, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (!x || !y || C % 8 != 0) return op_done("fav_op_maxpool3x3s2: bad argument");
+    launch_maxpool(nullptr, x, y, n, H, W, C, (hipStream_t)stream);
+    return op_done(nullptr);
+}
+
+fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t C, const fav_dropout_desc* drop, void* stream) {
+    if (!x || !y || C % 8 != 0 || HW < 1) return op_done("fav_op_avgpool: bad argument");
+    launch_avgpool(nullptr, x, y, n, HW, C, make_drop(drop), (hipStream_t)stream);
+    return op_done(nullptr);
+}
+
+fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems, int32_t n_out, const fav_dropout_desc* drop, void* stream) {
+    if (!x || !out || !drop || drop->site < 0 || elems % 8 != 0) return op_done("fav_op_entry_dropout: bad argument");
+    launch_entry_dropout(nullptr, x, out, elems, n_out, make_drop(drop), (hipStream_t)stream);
+    return op_done(nullptr);
+}
+
+fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t C, int32_t ld, float temperature, int32_t kind,
+                       float tau, int32_t* labels, float* conf, uint8_t* fail, float* score, void* stream) {
+    if (!logits || !labels || !conf || T < 1 || n < 1 || !(temperature > 0.f)) return op_done("fav_op_head: bad argument");
+    return op_done(launch_head(nullptr, logits, T, n, C, ld, temperature, kind, tau, labels, conf, fail, score, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Batch sharding across the GPUs of one node.
+
+Every frame is independent (BatchNorm is folded, dropout masks are keyed by the
+GLOBAL frame index), so rank r classifies frames [start_r, stop_r) of the batch
+with fully replicated weights and the only exchange is one small all-gather of
+packed 8-byte (int32 label, fp32 confidence) records — 2 KiB for 256 frames,
+latency-bound on xGMI, so a single ``all_gather_into_tensor`` (RCCL when the
+backend is "nccl") and no ring/bucket machinery.  The reference is a single
+process (SURVEY.md §5 "Distributed communication backend: None").
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous shard [start, stop) of rank; the first n_total % world ranks get one extra frame."""
+    q, r = divmod(int(n_total), int(world))
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def pack_records(labels, conf):
+    """(int32[n], fp32[n]) torch tensors -> int32[n, 2] records (confidence bit-cast)."""
+    import torch
+    return torch.stack([labels.to(torch.int32), conf.to(torch.float32).view(torch.int32)], dim=1).contiguous()
+
+
+def unpack_records(rec):
+    import torch
+    return rec[:, 0].contiguous(), rec[:, 1].contiguous().view(torch.float32)
+
+
+def classify_sharded(classify_fn, local_frames, n_total: int, rank: int, world: int, group=None):
+    """Each rank calls ``classify_fn(local_frames, first_index=start)`` on its own shard
+    and all ranks receive the full (labels[n_total], conf[n_total]).
+
+    ``classify_fn`` is ``Backend.classify`` on a GPU rank; results are gathered on the
+    device they live on (RCCL for CUDA tensors, gloo for CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    start, stop = shard_range(n_total, rank, world)
+    n_local = stop - start
+    if n_local > 0:
+        if int(local_frames.shape[0]) != n_local:
+            raise ValueError(f"rank {rank} owns frames [{start},{stop}) but was handed {int(local_frames.shape[0])}")
+        labels, conf = classify_fn(local_frames, first_index=start)
+        if isinstance(labels, np.ndarray):
+            labels, conf = torch.from_numpy(labels), torch.from_numpy(conf)
+        rec = pack_records(labels, conf)
+        dev = rec.device
+    else:
+        dev = local_frames.device if hasattr(local_frames, "device") and not isinstance(local_frames, np.ndarray) else "cpu"
+        rec = torch.zeros((0, 2), dtype=torch.int32, device=dev)
+    if world == 1:
+        return unpack_records(rec)
+    cap = -(-n_total // world)  # every shard padded to the largest
+    send = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+    send[:n_local] = rec
+    recv = torch.empty((world * cap, 2), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    parts = []
+    for r in range(world):
+        s, e = shard_range(n_total, r, world)
+        parts.append(recv[r * cap:r * cap + (e - s)])
+    return unpack_records(torch.cat(parts, dim=0))

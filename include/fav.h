@@ -1,0 +1,174 @@
+/* fav.h — C ABI of the MI355X-native failure-aware classification path.
+ *
+ * Drop-in boundary.  The reference has NO plugin / FFI API for
+ * this path: its seam is a plain Python method call whose result goes straight
+ * into the trust engine,
+ *
+ *     last_analysis = analyzer.analyze_frame(frame)         platform/backend/main.py:160
+ *     anomaly_score = anomaly.compute_anomaly(...)          platform/backend/main.py:141-143,347
+ *     state = engine.update(vision_status, anomaly_score, dt)   main.py:145,168,348
+ *
+ * so the entry points below are what a binding for that seam needs: create a
+ * per-connection scorer (main.py:110-118 constructs one per WebSocket), load a
+ * checkpoint, classify a batch of frames into (label, confidence), derive the
+ * failure flag / anomaly score the engine consumes, destroy on disconnect
+ * (main.py:310-317).  Conventions follow the reference's own: status codes and
+ * sentinels instead of exceptions (video_source.py:76-78,117; main.py:233-236),
+ * single caller per handle (one scorer per connection, main.py:117), caller
+ * owns every buffer it passes (video_source.py:114-117 hands out copies).
+ *
+ * Plain C types only; nothing of torch or HIP appears in a signature (a HIP
+ * stream travels as void*).  All *_dev pointers are device (HBM) addresses on
+ * the handle's device.
+ */
+#ifndef FAV_H
+#define FAV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAV_ABI_VERSION 1
+
+typedef struct fav_handle fav_handle;
+
+typedef enum fav_status {
+    FAV_OK = 0,
+    FAV_ERR_INVALID_ARG = 1,
+    FAV_ERR_BAD_BLOB = 2,
+    FAV_ERR_NO_WEIGHTS = 3,
+    FAV_ERR_HIP = 4,        /* a HIP runtime call failed; see fav_last_error() */
+    FAV_ERR_NO_DEVICE = 5,  /* no usable gfx950 device: the path has no CPU fallback */
+    FAV_ERR_UNSUPPORTED = 6
+} fav_status;
+
+/* Frame layout handed to fav_classify.  NHWC_U8 is the reference's frame
+ * format (np.uint8 HxWx3, signal_analyzer.py:47-58; video_source.py:144-148);
+ * NHWC_F32 carries [0,1] pixels (corrupted frames that are not 8-bit). */
+typedef enum fav_layout { FAV_LAYOUT_NHWC_U8 = 0, FAV_LAYOUT_NHWC_F32 = 1 } fav_layout;
+typedef enum fav_arch { FAV_ARCH_RESNET18_CIFAR = 0, FAV_ARCH_RESNET50 = 1 } fav_arch;
+typedef enum fav_conf_kind { FAV_CONF_MAX_SOFTMAX = 0, FAV_CONF_ENTROPY = 1 } fav_conf_kind;
+/* FAV_MATH_BF16: bf16 MFMA, fp32 accumulate (production).
+ * FAV_MATH_F32_EXACT: same bf16 operands fed to the fp32-input MFMA, whose
+ * result is a k-ordered fmaf chain; bit-reproducible against oracle/ (validation). */
+typedef enum fav_math_mode { FAV_MATH_BF16 = 0, FAV_MATH_F32_EXACT = 1 } fav_math_mode;
+
+typedef struct fav_config {
+    uint32_t struct_size;   /* sizeof(fav_config), for ABI growth */
+    int32_t device;         /* HIP device ordinal */
+    int32_t arch;           /* fav_arch */
+    int32_t num_classes;
+    int32_t in_h, in_w;     /* frame size */
+    int32_t max_batch;      /* largest n passed to fav_classify */
+    float mean[3];          /* per-channel normalisation on [0,1] pixels */
+    float stdev[3];
+    int32_t n_samples;      /* MC-Dropout T; 1 = single deterministic pass */
+    uint32_t site_mask;     /* bit s<n_blocks: output of residual block s; bit n_blocks: pooled features */
+    float dropout_p;
+    uint64_t seed;          /* Philox key */
+    float temperature;      /* softmax(z / temperature) */
+    int32_t conf_kind;      /* fav_conf_kind */
+    float tau;              /* failure threshold: fail = conf < tau */
+    int32_t math_mode;      /* fav_math_mode */
+    int32_t chunk_a;        /* frames per pass through the high-resolution stages (0 = auto) */
+    int32_t chunk_b;        /* frames per pass through the low-resolution stages (0 = auto) */
+    int32_t regroup_block;  /* first residual block of the low-resolution group (-1 = auto) */
+} fav_config;
+
+/* Fills *cfg with the defaults (ImageNet mean/std, T=1, no dropout, tau=0.5). */
+void fav_default_config(fav_config* cfg, int32_t arch);
+
+/* Lifecycle: create -> load_weights -> classify xN -> destroy
+ * (reference lifecycle: construct on accept main.py:110-118, reset main.py:284-291,
+ * drop on disconnect main.py:310-317). */
+fav_status fav_create(const fav_config* cfg, fav_handle** out);
+fav_status fav_load_weights(fav_handle* h, const void* blob_host, size_t size);
+void fav_destroy(fav_handle* h);
+const char* fav_last_error(const fav_handle* h); /* h may be NULL: error of the last failed fav_create */
+int32_t fav_abi_version(void);
+
+/* The hot path: n frames -> labels[n] (int32), conf[n] (fp32), both device
+ * pointers.  Asynchronous on `hip_stream` (NULL = the default stream); results
+ * are complete once the stream is synchronised.  Replaces the scorer call at
+ * main.py:160 / main.py:141. */
+fav_status fav_classify(fav_handle* h, const void* images_dev, int32_t n, int32_t layout,
+                        int32_t* labels_dev, float* conf_dev, void* hip_stream);
+
+/* Same, plus: first_image_index (global index of frame 0 of this call — dropout
+ * masks are keyed by global frame index so a sharded batch reproduces the
+ * unsharded result), fail_dev[n] (uint8: conf < tau) and
+ * score_dev[n] (fp32 anomaly_score = clamp(1 - conf, 0, 1), the value fed to
+ * TrustEngine.update, trust_engine.py:139).  fail_dev / score_dev may be NULL. */
+fav_status fav_classify_ex(fav_handle* h, const void* images_dev, int32_t n, int32_t layout,
+                           int64_t first_image_index, int32_t* labels_dev, float* conf_dev,
+                           uint8_t* fail_dev, float* score_dev, void* hip_stream);
+
+/* Host-buffer convenience (frames and results in host memory; synchronous). */
+fav_status fav_classify_host(fav_handle* h, const void* images_host, int32_t n, int32_t layout,
+                             int64_t first_image_index, int32_t* labels_host, float* conf_host,
+                             uint8_t* fail_host, float* score_host);
+
+/* Logits of the last fav_classify call, copied to logits_dev as fp32
+ * [T][n][num_classes] (T = 1 without dropout).  Parity tests use it. */
+fav_status fav_get_logits(fav_handle* h, float* logits_dev, int32_t* t_out, int32_t* n_out, void* hip_stream);
+
+/* Per-kernel-class timing with HIP events on the launch stream (bench.py's
+ * roofline leg).  Classes: see fav_kernel_class. */
+typedef enum fav_kernel_class {
+    FAV_K_STEM = 0, FAV_K_CONV = 1, FAV_K_MAXPOOL = 2, FAV_K_AVGPOOL = 3,
+    FAV_K_DROPOUT = 4, FAV_K_HEAD = 5, FAV_K_COUNT = 6
+} fav_kernel_class;
+typedef struct fav_profile {
+    double ms[FAV_K_COUNT];        /* summed event-measured duration per class */
+    double flops[FAV_K_COUNT];     /* algorithmic FLOPs launched */
+    double bytes[FAV_K_COUNT];     /* algorithmic HBM bytes launched */
+    int64_t launches[FAV_K_COUNT];
+} fav_profile;
+fav_status fav_set_profiling(fav_handle* h, int32_t enable);
+fav_status fav_get_profile(fav_handle* h, fav_profile* out, int32_t reset); /* synchronises the device */
+
+/* ---- Operator level (one launch each; used by the executor and by the
+ * per-kernel parity tests).  All tensors NHWC, bf16 unless noted. ---- */
+typedef struct fav_dropout_desc {
+    int32_t site;            /* -1 = no dropout */
+    uint32_t threshold;      /* drop iff 16-bit draw < threshold */
+    float scale;             /* 1 / (1 - threshold/65536) */
+    uint64_t seed;
+    int64_t v0;              /* virtual frame index of row 0: v = t * n_img + i */
+    int32_t n_img;           /* frames per sample */
+    int64_t first_image_index;
+} fav_dropout_desc;
+
+typedef struct fav_conv_desc {
+    const void* x;           /* [n_frames][H][W][Cin] bf16, Cin % 64 == 0 */
+    const void* w;           /* [Cout][kh][kw][Cin] bf16, Cout % 64 == 0 */
+    const float* bias;       /* [Cout] */
+    const void* res;         /* optional [n_frames][Ho][Wo][Cout] bf16 */
+    void* y;                 /* [n_frames][Ho][Wo][Cout] bf16, or fp32 if out_f32 */
+    int32_t n_frames, H, W, Cin, Cout, kh, kw, stride, pad;
+    int32_t relu, out_f32, math_mode;
+    fav_dropout_desc drop;
+} fav_conv_desc;
+fav_status fav_op_conv2d(const fav_conv_desc* d, void* hip_stream);
+/* frames (u8 or fp32 NHWC3) -> normalised bf16 im2col matrix [n*Ho*Wo][kpad] */
+fav_status fav_op_stem_im2col(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W,
+                              int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t kpad,
+                              const float* mean3, const float* inv_std3, void* out, void* hip_stream);
+fav_status fav_op_maxpool3x3s2(const void* x, void* y, int32_t n, int32_t H, int32_t W, int32_t C, void* hip_stream);
+fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t C,
+                          const fav_dropout_desc* drop, void* hip_stream);
+/* out[v - v0][e] = dropout(x[v % n_img][e]) for v in [v0, v0 + n_out) */
+fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems_per_frame, int32_t n_out,
+                                const fav_dropout_desc* drop, void* hip_stream);
+/* logits fp32 [T][n][ld] -> labels, conf (and fail/score if non-NULL) */
+fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t num_classes, int32_t ld,
+                       float temperature, int32_t conf_kind, float tau,
+                       int32_t* labels, float* conf, uint8_t* fail, float* score, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAV_H */

@@ -1,0 +1,178 @@
+"""End-to-end parity of Backend.classify (HIP, through the C ABI) against the CPU
+oracle, plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerances.  The reference pins nothing on this path (parity
+unpinned), so the oracle is the spec.  Two bf16 pipelines that sum in different
+orders differ by one bf16 ulp on a growing fraction of activations (a flipped
+rounding perturbs every downstream sum; tests/test_oracle.py shows the same between
+the NumPy oracle and torch-CPU), so end-to-end:
+  * labels must be equal wherever the oracle's top-2 probability gap exceeds GAP_TOL,
+  * confidences within CONF_TOL,
+  * logits within LOGIT_RMS_TOL of the oracle's in rms relative to their spread.
+Per-kernel parity (tests/test_gpu_ops.py) is tight; the exact math mode
+(test_gpu_exact.py) is bit-for-bit.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from failure_aware_vision_amd import Backend, synth, weights  # noqa: E402
+from failure_aware_vision_amd._lib import FavError  # noqa: E402
+from oracle import fav_oracle as O  # noqa: E402
+
+GAP_TOL = 0.08
+CONF_TOL = 0.08
+LOGIT_RMS_TOL = 0.05
+
+
+def check_against_oracle(be, model, frames, ocfg, first_index=0):
+    if isinstance(frames, np.ndarray):
+        dev_frames = torch.from_numpy(frames).cuda()
+    labels, conf = be.classify(dev_frames, first_index=first_index)
+    lg = be.logits()
+    torch.cuda.synchronize()
+    ids = np.arange(first_index, first_index + frames.shape[0])
+    ol, oc, olg, opb = O.classify(model, frames, ocfg, img_ids=ids, return_logits=True)
+    l, c, g = labels.cpu().numpy(), conf.cpu().numpy(), lg.cpu().numpy()
+    assert g.shape == olg.shape
+    rms = np.sqrt(((g - olg) ** 2).mean()) / olg.std()
+    assert rms < LOGIT_RMS_TOL, f"logit rms error {rms:.4f}"
+    srt = np.sort(opb, axis=1)
+    gap = srt[:, -1] - srt[:, -2]
+    bad = (l != ol) & (gap >= GAP_TOL)
+    assert not bad.any(), f"labels differ beyond tolerance at {np.nonzero(bad)[0]}: {l[bad]} vs {ol[bad]}, gap {gap[bad]}"
+    assert np.abs(c - oc).max() < CONF_TOL, np.abs(c - oc).max()
+    return (l == ol).mean(), rms
+
+
+def test_resnet18_config1_single_pass(r18_blob):
+    """BASELINE config 1 shape (ResNet-18, 32x32, batch 32, max-softmax), on the GPU."""
+    blob, _ = r18_blob
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(32, 32, 32, seed=7)
+    be = Backend("resnet18_cifar", blob, max_batch=32)
+    agree, rms = check_against_oracle(be, model, frames, O.ClassifyConfig())
+    assert agree >= 0.9
+    # fp32 [0,1] frames take the other layout branch and must give the same answer as u8
+    l1, c1 = be.classify(torch.from_numpy(frames).cuda())
+    l2, c2 = be.classify(torch.from_numpy(frames.astype(np.float32) * np.float32(1 / 255.0)).cuda())
+    assert torch.equal(l1, l2) and torch.equal(c1, c2)
+    # numpy in -> numpy out through fav_classify_host
+    l3, c3 = be.classify(frames)
+    assert np.array_equal(l3, l1.cpu().numpy()) and np.array_equal(c3, c1.cpu().numpy())
+    be.close()
+
+
+@pytest.mark.parametrize("policy", ["last_layer", "layer4+fc", "all_blocks"])
+def test_resnet18_mc_dropout(r18_blob, policy):
+    blob, _ = r18_blob
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(12, 32, 32, seed=8)
+    mask = weights.site_mask_for(0, policy)
+    be = Backend("resnet18_cifar", blob, max_batch=12, n_samples=5, dropout_policy=policy, dropout_p=0.1, seed=4,
+                 conf_kind="entropy", chunk_a=7, chunk_b=16)  # ragged chunks on purpose
+    ocfg = O.ClassifyConfig(n_samples=5, site_mask=mask, p=0.1, seed=4, conf_kind=O.CONF_ENTROPY)
+    check_against_oracle(be, model, frames, ocfg, first_index=1000)
+    assert be.logits().shape == (5, 12, 10)
+    be.close()
+
+
+def test_resnet50_small_frames(r50_blob):
+    """ResNet-50 on 64x64 frames: every layer shape class (7x7/2 stem, 3x3/2, 1x1/2
+    downsample, bottleneck residuals) at a size the oracle finishes in seconds."""
+    blob, _ = r50_blob
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(6, 64, 64, seed=9)
+    be = Backend("resnet50", blob, in_hw=(64, 64), max_batch=6)
+    check_against_oracle(be, model, frames, O.ClassifyConfig())
+    be.close()
+    be = Backend("resnet50", blob, in_hw=(64, 64), max_batch=6, n_samples=3, dropout_policy="all_blocks",
+                 dropout_p=0.1, seed=4)
+    ocfg = O.ClassifyConfig(n_samples=3, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4)
+    check_against_oracle(be, model, frames, ocfg, first_index=17)
+    be.close()
+
+
+def test_resnet50_224_vs_oracle(r50_blob):
+    """BASELINE config 2/3 frame size, small batch: clean and Gaussian-noise severity 3."""
+    blob, _ = r50_blob
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(8, 224, 224, seed=7)
+    be = Backend("resnet50", blob, max_batch=8)
+    check_against_oracle(be, model, frames, O.ClassifyConfig())
+    noisy = synth.gaussian_noise_f32(frames, 3, seed=3)
+    labels, conf = be.classify(torch.from_numpy(noisy).cuda())
+    ol, oc, olg, opb = O.classify(model, noisy, O.ClassifyConfig(), return_logits=True)
+    srt = np.sort(opb, axis=1)
+    gap = srt[:, -1] - srt[:, -2]
+    l = labels.cpu().numpy()
+    assert np.all((l == ol) | (gap < GAP_TOL))
+    assert np.abs(conf.cpu().numpy() - oc).max() < CONF_TOL
+    be.close()
+
+
+def test_full_size_properties(r50_blob):
+    """BASELINE headline shape (ResNet-50, 224x224, batch 256, MC-Dropout): properties
+    that need no oracle run.  (a) determinism; (b) shard invariance: two half batches
+    with first_image_index give bit-identical results (what the 8-GPU path relies on,
+    SURVEY.md §8e); (c) chunking invariance: pass sizes change the schedule, not the
+    result; (d) a frame's result does not depend on its neighbours."""
+    blob, _ = r50_blob
+    n, T = 256, 4
+    frames = torch.from_numpy(synth.synthetic_frames_u8(n, 224, 224, seed=21)).cuda()
+    kw = dict(n_samples=T, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    be = Backend("resnet50", blob, max_batch=n, **kw)
+    l0, c0 = be.classify(frames)
+    lg0 = be.logits()
+    l1, c1 = be.classify(frames)
+    assert torch.equal(l0, l1) and torch.equal(c0, c1)
+    la, ca = be.classify(frames[:128], first_index=0)
+    lb, cb = be.classify(frames[128:], first_index=128)
+    assert torch.equal(torch.cat([la, lb]), l0) and torch.equal(torch.cat([ca, cb]), c0)
+    assert len(set(l0.cpu().tolist())) > 20          # not a degenerate model
+    assert lg0.shape == (T, n, 1000) and torch.isfinite(lg0).all()
+    assert not torch.equal(lg0[0], lg0[1])            # samples really differ
+    be.close()
+    be2 = Backend("resnet50", blob, max_batch=n, chunk_a=24, chunk_b=200, regroup_block=10, **kw)
+    l2, c2 = be2.classify(frames)
+    assert torch.equal(l2, l0) and torch.equal(c2, c0)
+    perm = torch.arange(n - 1, -1, -1, device="cuda")
+    # reversed batch with the same global indices is not expressible (indices are
+    # positional), so check neighbour-independence with dropout off instead
+    be2.close()
+    be3 = Backend("resnet50", blob, max_batch=n)
+    l3, c3 = be3.classify(frames)
+    l4, c4 = be3.classify(frames[perm])
+    assert torch.equal(l4, l3[perm]) and torch.equal(c4, c3[perm])
+    be3.close()
+
+
+def test_error_behaviour(r18_blob):
+    blob, _ = r18_blob
+    with pytest.raises(FavError) as e:
+        Backend("resnet18_cifar", blob[:1000], max_batch=4)
+    assert "BAD_BLOB" in str(e.value)
+    bad = bytearray(blob); bad[0] ^= 0xFF
+    with pytest.raises(FavError):
+        Backend("resnet18_cifar", bytes(bad), max_batch=4)
+    with pytest.raises(FavError):                       # resnet50 handle, resnet18 blob
+        Backend("resnet50", blob, max_batch=4, in_hw=(64, 64))
+    be = Backend("resnet18_cifar", blob, max_batch=4)
+    with pytest.raises(FavError) as e:
+        be.classify(torch.zeros((5, 32, 32, 3), dtype=torch.uint8, device="cuda"))
+    assert "max_batch" in str(e.value)
+    with pytest.raises(ValueError):
+        be.classify(torch.zeros((2, 16, 32, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(TypeError):
+        be.classify(torch.zeros((2, 32, 32, 3), dtype=torch.float16, device="cuda"))
+    with pytest.raises(FavError):
+        Backend("resnet18_cifar", blob, max_batch=4, temperature=0.0)
+    # the seam adapter: the dict shape of SignalAnalyzer.analyze_frame
+    frame = synth.synthetic_frame_u8(32, 32, 1, 0)
+    out = be.analyze_frame(frame)
+    assert set(out) == {"anomaly_score", "vision_status", "metrics"}
+    assert 0.0 <= out["anomaly_score"] <= 1.0 and out["vision_status"] == "VISION_OK"
+    assert abs(out["anomaly_score"] - (1 - out["metrics"]["confidence"])) < 1e-3
+    be.close()

@@ -1,0 +1,235 @@
+"""Per-kernel parity: every HIP kernel, called through the C ABI (fav_op_*), against
+the CPU oracle on the same seeded inputs.  One kernel = one rounding point, so the
+bar is tight: integer/bf16-exact where the arithmetic is order-free (im2col, pools,
+dropout masks, labels), and at most one bf16 ulp on well under 1% of elements for
+the MFMA convolution (fp32 summation order is the only difference)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from failure_aware_vision_amd import _lib  # noqa: E402
+from oracle import fav_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return _lib.load()
+
+
+def dev_bf16(x):
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda().to(torch.bfloat16).contiguous()
+
+
+def host_f32(t):
+    return t.to(torch.float32).cpu().numpy()
+
+
+def drop_desc(site=-1, thr=0, scale=1.0, seed=0, v0=0, n_img=1, first=0):
+    return _lib.FavDropoutDesc(site, thr, scale, seed, v0, n_img, first)
+
+
+def run_conv(lib, x, w, b, res=None, stride=1, pad=0, relu=1, out_f32=0, math_mode=0, drop=None):
+    n, H, W, cin = x.shape
+    cout, kh, kw, _ = w.shape
+    ho, wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    xd, wd = dev_bf16(x), dev_bf16(w)
+    bd = torch.from_numpy(b.astype(np.float32)).cuda()
+    rd = dev_bf16(res) if res is not None else None
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    d = _lib.FavConvDesc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None,
+                         y.data_ptr(), n, H, W, cin, cout, kh, kw, stride, pad, relu, out_f32, math_mode,
+                         drop or drop_desc())
+    _lib.check(lib.fav_op_conv2d(C.byref(d), None))
+    torch.cuda.synchronize()
+    return host_f32(y)
+
+
+def assert_one_ulp(got, ref, frac=0.01):
+    d = np.abs(got - ref)
+    assert (d > 0).mean() < frac, f"{(d > 0).mean():.4f} of elements differ"
+    assert np.all(d <= np.maximum(np.abs(got), np.abs(ref)) * 2.0 ** -7 + 1e-5), d.max()
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, H, W, n, residual
+    (64, 64, 1, 1, 0, 14, 14, 3, False),
+    (64, 64, 3, 1, 1, 13, 9, 2, False),
+    (64, 128, 3, 2, 1, 15, 15, 2, False),
+    (128, 256, 1, 1, 0, 7, 7, 5, True),
+    (256, 512, 1, 2, 0, 14, 14, 2, False),
+    (128, 128, 3, 1, 1, 28, 28, 2, True),
+    (512, 128, 1, 1, 0, 5, 5, 1, False),      # M=25: a single partial tile
+    (192, 64, 1, 1, 0, 16, 16, 2, False),     # the stem GEMM shape (K=192)
+    (64, 64, 3, 1, 1, 56, 56, 1, True),       # 25 tiles, tail tile of 64 rows
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,n,use_res", CONV_CASES)
+def test_conv2d_bf16_vs_oracle(lib, cin, cout, k, stride, pad, H, W, n, use_res):
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    x = O.bf16_round(np.maximum(rng.standard_normal((n, H, W, cin)), -0.5).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32))
+    b = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    L = O.ConvLayer(cout, cin, k, k, stride, pad, w, b)
+    acc = O.conv_acc(x, L)
+    res = O.bf16_round(rng.standard_normal(acc.shape).astype(np.float32)) if use_res else None
+    ref = O.epilogue(acc, b, res=res, relu=True)
+    got = run_conv(lib, x, w, b, res, stride, pad, relu=1)
+    assert got.shape == ref.shape
+    assert_one_ulp(got, ref)
+    # no-ReLU variant (downsample path) and fp32 output (classifier)
+    got2 = run_conv(lib, x, w, b, None, stride, pad, relu=0)
+    assert_one_ulp(got2, O.epilogue(acc, b, relu=False))
+    got3 = run_conv(lib, x, w, b, None, stride, pad, relu=0, out_f32=1)
+    np.testing.assert_allclose(got3, acc + b, rtol=2e-5, atol=2e-5)
+
+
+def test_conv2d_exact_input_catches_transposes(lib):
+    """Integer-valued operands (every product and sum exact in fp32) with asymmetric
+    weights: any swapped row/column/k mapping in the MFMA fragment code shows up as an
+    exact mismatch, independent of rounding."""
+    rng = np.random.default_rng(7)
+    n, H, W, cin, cout = 1, 12, 12, 128, 256
+    x = rng.integers(-3, 4, (n, H, W, cin)).astype(np.float32)
+    w = rng.integers(-2, 3, (cout, 3, 3, cin)).astype(np.float32)
+    b = rng.integers(-4, 5, cout).astype(np.float32)
+    L = O.ConvLayer(cout, cin, 3, 3, 1, 1, w, b)
+    ref = O.conv_acc(x, L) + b
+    for mode in (0, 1):
+        got = run_conv(lib, x, w, b, None, 1, 1, relu=0, out_f32=1, math_mode=mode)
+        assert np.array_equal(got, ref), f"math_mode {mode}: max diff {np.abs(got - ref).max()}"
+
+
+def test_conv2d_fused_dropout_mask_is_philox(lib):
+    rng = np.random.default_rng(9)
+    n, H, W, cin, cout = 6, 7, 7, 64, 128
+    x = O.bf16_round(np.abs(rng.standard_normal((n, H, W, cin))).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((cout, 1, 1, cin)) * 0.2).astype(np.float32))
+    b = np.full(cout, 0.5, np.float32)
+    L = O.ConvLayer(cout, cin, 1, 1, 1, 0, w, b)
+    thr = O.dropout_threshold(0.25)
+    scale = O.dropout_scale(thr)
+    # rows are virtual frames v0..v0+5 of a 4-frame batch: v=5,6,7 -> t=1 (img 1..3), v=8,9,10 -> t=2
+    v0, n_img, first, seed, site = 5, 4, 100, 0x1234567890ABCDEF, 3
+    keep = np.empty((n, H * W * cout), bool)
+    for i in range(n):
+        v = v0 + i
+        keep[i] = O.dropout_keep(seed, v // n_img, site, np.array([first + v % n_img]), H * W * cout, thr)[0]
+    ref = O.epilogue(O.conv_acc(x, L), b, relu=True, keep=keep, scale=scale)
+    got = run_conv(lib, x, w, b, None, 1, 0, relu=1, drop=drop_desc(site, thr, float(scale), seed, v0, n_img, first))
+    assert np.array_equal(got == 0, ref == 0), "dropout mask differs from the oracle's Philox mask"
+    assert abs((got == 0).mean() - 0.25) < 0.02
+    assert_one_ulp(got, ref)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("k,stride,pad,kpad,H,W", [(7, 2, 3, 192, 32, 40), (3, 1, 1, 64, 16, 16)])
+def test_stem_im2col_exact(lib, layout, k, stride, pad, kpad, H, W):
+    rng = np.random.default_rng(3)
+    n = 3
+    if layout == 0:
+        img = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    else:
+        img = rng.random((n, H, W, 3), dtype=np.float32)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    istd = O.inv_std32(std)
+    xn = O.normalize_input(img, mean, istd)
+    cols, ho, wo = O._im2col(xn, k, k, stride, pad)
+    ref = np.zeros((cols.shape[0], kpad), np.float32)
+    ref[:, :cols.shape[1]] = cols
+    out = torch.empty((n * ho * wo, kpad), dtype=torch.bfloat16, device="cuda")
+    m3 = (C.c_float * 3)(*mean)
+    i3 = (C.c_float * 3)(*[float(v) for v in istd])
+    _lib.check(lib.fav_op_stem_im2col(torch.from_numpy(img).cuda().data_ptr(), layout, n, H, W, k, k, stride, pad, kpad,
+                                      m3, i3, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(host_f32(out), ref)
+
+
+def test_maxpool_exact(lib):
+    rng = np.random.default_rng(4)
+    for (n, H, W, Cc) in [(2, 16, 16, 64), (1, 15, 9, 128), (3, 112, 112, 64)]:
+        x = O.bf16_round(rng.standard_normal((n, H, W, Cc)).astype(np.float32))
+        ref = O.maxpool3x3s2(x)
+        y = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.fav_op_maxpool3x3s2(dev_bf16(x).data_ptr(), y.data_ptr(), n, H, W, Cc, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(host_f32(y), ref)
+
+
+def test_avgpool_exact_and_dropout(lib):
+    rng = np.random.default_rng(5)
+    n, HW, Cc = 5, 49, 512
+    x = O.bf16_round(np.abs(rng.standard_normal((n, 7, 7, Cc))).astype(np.float32))
+    ref = O.bf16_round(O.global_avgpool(x))
+    y = torch.empty((n, Cc), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.fav_op_avgpool(dev_bf16(x).data_ptr(), y.data_ptr(), n, HW, Cc, None, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(host_f32(y), ref)  # same sequential fp32 order -> bit exact
+    thr = O.dropout_threshold(0.5)
+    scale = O.dropout_scale(thr)
+    d = drop_desc(16, thr, float(scale), 77, 2, 5, 40)   # v = 2..6 of a 5-frame batch
+    keep = np.stack([O.dropout_keep(77, (2 + i) // 5, 16, np.array([40 + (2 + i) % 5]), Cc, thr)[0] for i in range(n)])
+    ref2 = O.bf16_round(np.where(keep, O.global_avgpool(x) * scale, 0).astype(np.float32))
+    _lib.check(lib.fav_op_avgpool(dev_bf16(x).data_ptr(), y.data_ptr(), n, HW, Cc, C.byref(d), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(host_f32(y), ref2)
+
+
+def test_entry_dropout_exact(lib):
+    rng = np.random.default_rng(6)
+    n_img, E, n_out, v0 = 3, 7 * 7 * 64, 7, 2
+    x = O.bf16_round(np.abs(rng.standard_normal((n_img, E))).astype(np.float32))
+    thr = O.dropout_threshold(0.1)
+    scale = O.dropout_scale(thr)
+    d = drop_desc(2, thr, float(scale), 5, v0, n_img, 9)
+    out = torch.empty((n_out, E), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.fav_op_entry_dropout(dev_bf16(x).data_ptr(), out.data_ptr(), E, n_out, C.byref(d), None))
+    torch.cuda.synchronize()
+    ref = np.empty((n_out, E), np.float32)
+    for i in range(n_out):
+        v = v0 + i
+        keep = O.dropout_keep(5, v // n_img, 2, np.array([9 + v % n_img]), E, thr)[0]
+        ref[i] = O.bf16_round(np.where(keep, x[v % n_img] * scale, 0).astype(np.float32))
+    assert np.array_equal(host_f32(out), ref)
+
+
+@pytest.mark.parametrize("T,n,Cc,ld", [(1, 5, 1000, 1024), (30, 9, 1000, 1024), (3, 4, 10, 64), (7, 3, 257, 320)])
+def test_head_vs_oracle(lib, T, n, Cc, ld):
+    rng = np.random.default_rng(T * 100 + Cc)
+    lg = np.zeros((T, n, ld), np.float32)
+    lg[:, :, :Cc] = (rng.standard_normal((T, n, Cc)) * 4).astype(np.float32)
+    lg[:, :, Cc:] = 1e9  # padding columns must be ignored
+    for kind in (0, 1):
+        rl, rc, pbar = O.confidence_head(lg[:, :, :Cc], temperature=1.3, kind=kind)
+        rf, rs = O.failure_detect(rc, 0.4)
+        ld_t = torch.from_numpy(lg).cuda()
+        labels = torch.empty(n, dtype=torch.int32, device="cuda")
+        conf = torch.empty(n, dtype=torch.float32, device="cuda")
+        fail = torch.empty(n, dtype=torch.uint8, device="cuda")
+        score = torch.empty(n, dtype=torch.float32, device="cuda")
+        _lib.check(lib.fav_op_head(ld_t.data_ptr(), T, n, Cc, ld, 1.3, kind, 0.4, labels.data_ptr(), conf.data_ptr(),
+                                   fail.data_ptr(), score.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(labels.cpu().numpy(), rl)
+        np.testing.assert_allclose(conf.cpu().numpy(), rc, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(score.cpu().numpy(), rs, rtol=0, atol=2e-6)
+        near = np.abs(rc - 0.4) < 1e-5
+        assert np.array_equal(fail.cpu().numpy()[~near], rf[~near])
+
+
+def test_head_tie_breaks_to_lowest_index(lib):
+    lg = np.zeros((1, 2, 64), np.float32)
+    lg[0, 0, [40, 7, 23]] = 2.0
+    lg[0, 1, :] = 0.0
+    labels = torch.empty(2, dtype=torch.int32, device="cuda")
+    conf = torch.empty(2, dtype=torch.float32, device="cuda")
+    _lib.check(lib.fav_op_head(torch.from_numpy(lg).cuda().data_ptr(), 1, 2, 50, 64, 1.0, 0, 0.5, labels.data_ptr(),
+                               conf.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    assert labels.cpu().tolist() == [7, 0]

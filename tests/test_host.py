@@ -1,0 +1,129 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/fav.h
+declares, the ctypes mirror of fav_config matches the C layout, the product path
+fails loudly without a GPU, and the shard/gather logic of the N>1 path is correct
+under a 2-rank gloo group (the per-rank classifier is stood in for by the oracle,
+used here as the checker's input, never shipped)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from failure_aware_vision_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "fav.h")).read()
+    names = set(re.findall(r"\b(fav_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 18
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in fav.h but not exported"
+
+
+def test_config_struct_layout_and_defaults(lib):
+    from failure_aware_vision_amd import _lib
+    c = _lib.FavConfig()
+    lib.fav_default_config(C.byref(c), _lib.ARCH_RESNET50)
+    assert c.struct_size == C.sizeof(_lib.FavConfig)
+    assert (c.arch, c.num_classes, c.in_h, c.in_w, c.n_samples) == (1, 1000, 224, 224, 1)
+    assert abs(c.tau - 0.5) < 1e-7 and abs(c.temperature - 1.0) < 1e-7 and c.regroup_block == -1
+    assert np.allclose(list(c.mean), [0.485, 0.456, 0.406]) and np.allclose(list(c.stdev), [0.229, 0.224, 0.225])
+    lib.fav_default_config(C.byref(c), _lib.ARCH_RESNET18_CIFAR)
+    assert (c.num_classes, c.in_h) == (10, 32)
+    assert lib.fav_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from failure_aware_vision_amd import Backend, _lib
+    with pytest.raises(RuntimeError):
+        Backend("resnet18_cifar", b"", max_batch=1)
+    c = _lib.FavConfig()
+    lib.fav_default_config(C.byref(c), 0)
+    h = C.c_void_p()
+    st = lib.fav_create(C.byref(c), C.byref(h))
+    assert st == 5 and b"no CPU fallback" in lib.fav_last_error(None)
+    c.struct_size = 12
+    assert lib.fav_create(C.byref(c), C.byref(h)) == 1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "failure_aware_vision_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert not re.search(r"(CDLL|dlopen|open)\([^)]*oracle", src), f
+
+
+def test_shard_range_covers_batch():
+    from failure_aware_vision_amd import shard_range
+    for n in (1, 7, 8, 255, 256, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_site_masks():
+    from failure_aware_vision_amd import weights
+    assert weights.site_mask_for(1, "all_blocks") == 0xFFFF
+    assert weights.site_mask_for(1, "last_layer") == 1 << 16
+    assert weights.site_mask_for(1, "layer4+fc") == (1 << 12) | (1 << 13) | (1 << 14) | (1 << 16)
+    assert weights.site_mask_for(0, "all_blocks") == 0xFF
+    assert weights.site_mask_for(1, "none") == 0
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from failure_aware_vision_amd import classify_sharded, shard_range, synth, weights
+from oracle import fav_oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+blob, _ = weights.make_synthetic("resnet18_cifar", seed=1)
+model = O.parse_blob(blob)
+cfg = O.ClassifyConfig(n_samples=3, site_mask=weights.site_mask_for(0, "all_blocks"), p=0.1, seed=4)
+n = 11
+frames = synth.synthetic_frames_u8(n, 32, 32, seed=5)
+def stand_in(local, first_index=0):   # plays the per-rank Backend.classify
+    ids = np.arange(first_index, first_index + local.shape[0])
+    return O.classify(model, local, cfg, img_ids=ids)
+s, e = shard_range(n, rank, world)
+labels, conf = classify_sharded(stand_in, frames[s:e], n, rank, world)
+full_l, full_c = O.classify(model, frames, cfg)
+assert labels.dtype == torch.int32 and conf.dtype == torch.float32
+assert np.array_equal(labels.numpy(), full_l), (labels, full_l)
+assert np.array_equal(conf.numpy(), full_c)          # bit-for-bit: the gather moves bits, not values
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_classify_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
