@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the failure-aware classification path.
+
+Workload (BASELINE.json `metric`, configs[2]): ResNet-50, MC-Dropout T=30 (dropout
+after every residual block, p=0.1 — the `all_blocks` policy, 225.1 GFLOP per
+frame algorithmic with the deterministic prefix computed once), 224x224 frames
+with ImageNet-C style Gaussian noise severity 3, batch 256 per GPU.  A "step" is
+one classify() of one batch: frames resident in HBM -> (label, confidence) per
+frame.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every
+rank classifies its own 256-frame shard of a 256*N global batch (weak scaling) and
+the packed (label, confidence) records are all-gathered.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §6 for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RESNET50_GMAC = 4.089  # per frame, single pass
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_gflop_per_frame(policy: str, T: int) -> float:
+    prefix = {"none": RESNET50_GMAC, "all_blocks": 0.349, "layer4+fc": 3.278, "last_layer": 4.087}[policy]
+    if policy == "none":
+        return 2 * RESNET50_GMAC
+    return 2 * (prefix + T * (RESNET50_GMAC - prefix))
+
+
+def cpu_baseline(blob, args, T, policy):
+    """The oracle's torch-CPU port on a bounded sample of the same workload (same
+    weights, corruption, masks and prefix caching), timed on this host's cores."""
+    import torch
+    from failure_aware_vision_amd import synth, weights
+    from oracle import fav_oracle as O
+    from oracle import torch_cpu as TC
+    n = args.cpu_frames
+    frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(n, 224, 224, seed=21), 3, seed=3)
+    model = O.parse_blob(blob)
+    net = TC.TorchNet(model)
+    cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, policy), p=args.dropout_p, seed=4)
+    t0 = time.perf_counter()
+    TC.classify(model, frames, cfg, net=net)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames x T={T} ({policy}), oracle/torch_cpu.py fp32 MKL-DNN, one timed call of {dt:.1f} s",
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--samples", type=int, default=30, help="MC-Dropout T")
+    ap.add_argument("--policy", default="all_blocks", choices=["none", "last_layer", "layer4+fc", "all_blocks"])
+    ap.add_argument("--dropout-p", type=float, default=0.1)
+    ap.add_argument("--chunk-a", type=int, default=0)
+    ap.add_argument("--chunk-b", type=int, default=0)
+    ap.add_argument("--regroup-block", type=int, default=-1)
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from failure_aware_vision_amd import Backend, classify_sharded, synth, weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    T = args.samples if args.policy != "none" else 1
+    blob, info = weights.make_synthetic("resnet50", seed=1)
+    be = Backend("resnet50", blob, device=local_rank, max_batch=args.batch, n_samples=T, dropout_policy=args.policy,
+                 dropout_p=args.dropout_p if args.policy != "none" else 0.0, seed=4,
+                 chunk_a=args.chunk_a, chunk_b=args.chunk_b, regroup_block=args.regroup_block)
+    n_total = args.batch * world
+    start = rank * args.batch
+    frames_u8 = synth.synthetic_frames_u8(args.batch, 224, 224, seed=21, start_id=start)
+    frames = torch.from_numpy(synth.gaussian_noise_f32(frames_u8, 3, seed=3, start_id=start)).cuda()
+
+    def step():
+        return classify_sharded(be.classify, frames, n_total, rank, world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profile = not args.no_profile
+    if profile:
+        be.set_profiling(True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        labels, conf = step()
+        b.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lat_ms = [a.elapsed_time(b) for a, b in ev]
+    prof = be.get_profile() if profile else None
+    be.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        fps = n_total * args.steps / elapsed
+        gf = algorithmic_gflop_per_frame(args.policy, T)
+        out = {
+            "metric": "frames/sec, ResNet-50 MC-Dropout T=%d 224x224 batch=%d" % (T, args.batch),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "p50_latency_ms": statistics.median(lat_ms),
+            "config": {"workload": "BASELINE configs[2]: ResNet-50 v1.5 + MC-Dropout T=%d (%s, p=%.2f), 224x224x3 fp32 "
+                                   "frames with Gaussian noise severity 3, batch %d per GPU, synthetic frames and "
+                                   "seeded synthetic weights" % (T, args.policy, args.dropout_p, args.batch),
+                       "frames_per_gpu": args.batch, "global_batch": n_total, "mc_samples": T,
+                       "dropout_policy": args.policy, "algorithmic_gflop_per_frame": gf,
+                       "inputs": "resident in HBM before the timed region (H2D excluded)",
+                       "parallelism": "batch sharded, 1 process per GPU, all-gather of (label, confidence)"},
+            "achieved_tflops_algorithmic": fps * gf / 1000.0 / world,
+            "labels_distinct": int(len(set(labels.cpu().tolist()))),
+        }
+        if prof is not None:
+            cv = prof["conv_igemm"]
+            ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12 if cv["ms"] > 0 else 0.0
+            total_ms = sum(v["ms"] for v in prof.values())
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all conv/fc launches)",
+                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "avg_launch_us": 1000.0 * cv["ms"] / max(1, cv["launches"]),
+                               "launches": cv["launches"],
+                               "algorithmic_hbm_gbs": cv["bytes"] / (cv["ms"] * 1e-3) / 1e9 if cv["ms"] > 0 else 0.0,
+                               "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None}
+            out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+        if args.cpu_frames > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(blob, args, T, args.policy)
+                out["gpu_over_cpu"] = fps / world / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    be.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,13 @@ class FavProfile(C.Structure):
                 ("launches", C.c_int64 * K_COUNT)]
 
 
+class FavOpProfile(C.Structure):
+    _fields_ = [("op_index", C.c_int32), ("kind", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("stride", C.c_int32), ("reserved", C.c_int32), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double), ("launches", C.c_int64)]
+
+
 _SIGNATURES = {
     "fav_abi_version": (C.c_int32, []),
     "fav_default_config": (None, [C.POINTER(FavConfig), C.c_int32]),
@@ -68,6 +75,7 @@ _SIGNATURES = {
     "fav_get_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "fav_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "fav_get_profile": (C.c_int, [C.c_void_p, C.POINTER(FavProfile), C.c_int32]),
+    "fav_get_op_profile": (C.c_int, [C.c_void_p, C.POINTER(FavOpProfile), C.c_int32, C.POINTER(C.c_int32)]),
     "fav_op_conv2d": (C.c_int, [C.POINTER(FavConvDesc), C.c_void_p]),
     "fav_op_stem_im2col": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -163,6 +163,14 @@ class Backend:
         return {name: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i])
                 for i, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
 
+    def get_op_profile(self) -> list:
+        """Per-op rows of the static schedule (call after get_profile)."""
+        n = C.c_int32()
+        _lib.check(self.lib.fav_get_op_profile(self._h, None, 0, C.byref(n)), self._h)
+        arr = (_lib.FavOpProfile * n.value)()
+        _lib.check(self.lib.fav_get_op_profile(self._h, arr, n.value, C.byref(n)), self._h)
+        return [{f: getattr(r, f) for f, _ in _lib.FavOpProfile._fields_ if f != "reserved"} for r in arr]
+
     # -- the reference seam ----------------------------------------------------------
     def analyze_frame(self, frame: np.ndarray, status_provider=None) -> dict:
         """One uint8 HxWx3 frame -> the dict SignalAnalyzer.analyze_frame returns

@@ -108,7 +108,9 @@ struct fav_handle {
     void* host_stage = nullptr;     // for fav_classify_host
     // profiling
     bool profiling = false;
-    struct Ev { hipEvent_t a, b; int cls; };
+    struct Ev { hipEvent_t a, b; int cls; int op; };
+    std::vector<fav_op_profile> op_prof;   // one row per op of the static schedule
+    int cur_op = -1;
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     fav_profile prof{};
@@ -134,6 +136,12 @@ struct Prof {
         }
         idx = (int)h->ev_used++;
         h->ev_pool[idx].cls = cls;
+        h->ev_pool[idx].op = h->cur_op;
+        if (h->cur_op >= 0 && h->cur_op < (int)h->op_prof.size()) {
+            h->op_prof[h->cur_op].flops += flops;
+            h->op_prof[h->cur_op].bytes += bytes;
+            h->op_prof[h->cur_op].launches += 1;
+        }
         h->prof.flops[cls] += flops;
         h->prof.bytes[cls] += bytes;
         h->prof.launches[cls] += 1;
@@ -539,6 +547,7 @@ fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, i
         };
         for (int k = p.op_begin; k < p.op_end; ++k) {
             const Op& o = h->ops[k];
+            h->cur_op = k;
             fav_dropout_desc dd;
             dd.site = o.site; dd.threshold = thr; dd.scale = scale; dd.seed = c.seed;
             dd.v0 = p.suffix ? v0 : 0; dd.n_img = n; dd.first_image_index = first_index;
@@ -786,6 +795,15 @@ fav_status fav_set_profiling(fav_handle* h, int32_t enable) {
     h->profiling = enable != 0;
     h->ev_used = 0;
     memset(&h->prof, 0, sizeof h->prof);
+    h->op_prof.assign(h->ops.size(), fav_op_profile{});
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        const Op& o = h->ops[i];
+        fav_op_profile& r = h->op_prof[i];
+        r.op_index = (int)i; r.kind = (int)o.kind;
+        r.H = o.H; r.W = o.W; r.Cin = o.C; r.Ho = o.Ho; r.Wo = o.Wo; r.Cout = o.Co;
+        r.kh = r.kw = r.stride = 0;
+        if (o.layer >= 0) { const Layer& L = h->layers[o.layer]; r.kh = L.kh; r.kw = L.kw; r.stride = L.stride; }
+    }
     return FAV_OK;
 }
 
@@ -794,11 +812,22 @@ fav_status fav_get_profile(fav_handle* h, fav_profile* out, int32_t reset) {
     HIP_TRY(h, hipDeviceSynchronize());
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) == hipSuccess) h->prof.ms[h->ev_pool[i].cls] += ms;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) == hipSuccess) {
+            h->prof.ms[h->ev_pool[i].cls] += ms;
+            const int op = h->ev_pool[i].op;
+            if (op >= 0 && op < (int)h->op_prof.size()) h->op_prof[op].ms += ms;
+        }
     }
     h->ev_used = 0;
     *out = h->prof;
     if (reset) memset(&h->prof, 0, sizeof h->prof);
+    return FAV_OK;
+}
+
+fav_status fav_get_op_profile(fav_handle* h, fav_op_profile* out, int32_t cap, int32_t* n_out) {
+    if (!h || !n_out) return FAV_ERR_INVALID_ARG;
+    *n_out = (int32_t)h->op_prof.size();
+    if (out) for (int i = 0; i < cap && i < (int)h->op_prof.size(); ++i) out[i] = h->op_prof[i];
     return FAV_OK;
 }
 

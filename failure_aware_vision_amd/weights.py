@@ -114,8 +114,14 @@ def _conv64(x, w, stride, pad):
 
 
 def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = None,
-                   mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 6.0, n_calib: int = 16):
-    """Returns (blob bytes, info dict)."""
+                   mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 6.0, n_calib: int = 16,
+                   calib_dropout_p: float = 0.1):
+    """Returns (blob bytes, info dict).
+
+    The calibration batch is run twice through every layer — once as is, once with
+    Bernoulli(calib_dropout_p) dropout on every residual-block output — so the folded
+    statistics suit both the deterministic pass and the MC-Dropout passes (as a
+    network trained with dropout would)."""
     arch = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
     a = _ARCH[arch]
     if num_classes is None:
@@ -130,6 +136,8 @@ def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = Non
     for i in range(n_calib // 2, n_calib):
         x01[i] = synth.gaussian_noise_f32(frames[i:i + 1], 1 + i % 5, seed=0xCA11B, start_id=i)[0]
     x = (x01 - np.asarray(mean)) / np.asarray(std)
+    x = np.concatenate([x, x], axis=0)          # second half: the dropout pass
+    drop_rng = np.random.default_rng([int(seed), arch, 0xD0])
 
     folded = []  # (w_bf16_bits, b_fp32)
 
@@ -175,7 +183,10 @@ def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = Non
             idn = make_layer(spec, act)
             spec = next(it)
         act = np.maximum(branch + idn, 0.0)
-    feat = act.mean(axis=(1, 2))  # [n_calib, C]
+        if calib_dropout_p > 0:
+            keep = drop_rng.random(act[n_calib:].shape) >= calib_dropout_p
+            act[n_calib:] = np.where(keep, act[n_calib:] / (1.0 - calib_dropout_p), 0.0)
+    feat = act.mean(axis=(1, 2))  # [2*n_calib, C]
     # classifier: zero-mean rows (cancels the common-mode of the all-positive
     # features), gain chosen so calibration logits have the requested spread,
     # bias chosen so no class wins by default.

@@ -127,7 +127,16 @@ typedef struct fav_profile {
     double bytes[FAV_K_COUNT];     /* algorithmic HBM bytes launched */
     int64_t launches[FAV_K_COUNT];
 } fav_profile;
+/* One row per op of the static schedule (valid after fav_get_profile). */
+typedef struct fav_op_profile {
+    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout */
+    int32_t H, W, Cin, Ho, Wo, Cout, kh, kw, stride;
+    int32_t reserved;
+    double ms, flops, bytes;
+    int64_t launches;
+} fav_op_profile;
 fav_status fav_set_profiling(fav_handle* h, int32_t enable);
+fav_status fav_get_op_profile(fav_handle* h, fav_op_profile* out, int32_t cap, int32_t* n_out);
 fav_status fav_get_profile(fav_handle* h, fav_profile* out, int32_t reset); /* synchronises the device */
 
 /* ---- Operator level (one launch each; used by the executor and by the

@@ -182,11 +182,61 @@ def _im2col(x: np.ndarray, kh: int, kw: int, stride: int, pad: int):
     return patches.reshape(b * ho * wo, kh * kw * c), ho, wo
 
 
-def conv_acc(x: np.ndarray, L: ConvLayer) -> np.ndarray:
-    """fp32 accumulator of the convolution, [B,Ho,Wo,Cout] (no bias)."""
+_EXACT_LIB = None
+
+
+def _exact_lib():
+    """oracle/_build/libfav_exact.so: the accumulator in the HIP kernel's exact-mode order."""
+    global _EXACT_LIB
+    if _EXACT_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libfav_exact.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.dirname(os.path.abspath(__file__))])
+        lib = ctypes.CDLL(path)
+        lib.fav_exact_conv_acc.restype = ctypes.c_int
+        lib.fav_exact_conv_acc.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 9
+        _EXACT_LIB = lib
+    return _EXACT_LIB
+
+
+def conv_acc_exact(x: np.ndarray, w: np.ndarray, kh: int, kw: int, stride: int, pad: int) -> np.ndarray:
+    """Sequential-k fp32 accumulator (oracle/fav_exact.c).  x [B,H,W,C], w [N,kh,kw,C], C % 64 == 0."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    b, h, ww, c = x.shape
+    n = w.shape[0]
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (ww + 2 * pad - kw) // stride + 1
+    out = np.empty((b, ho, wo, n), np.float32)
+    rc = _exact_lib().fav_exact_conv_acc(x.ctypes.data, w.ctypes.data, out.ctypes.data, b, h, ww, c, n, kh, kw, stride, pad)
+    if rc != 0:
+        raise RuntimeError(f"fav_exact_conv_acc failed ({rc})")
+    return out
+
+
+def conv_acc(x: np.ndarray, L: ConvLayer, exact: bool = False) -> np.ndarray:
+    """fp32 accumulator of the convolution, [B,Ho,Wo,Cout] (no bias).
+    exact=False: im2col + BLAS sgemm (any summation order).
+    exact=True : the HIP kernel's exact-mode order, bit-reproducible (fav_exact.c);
+                 a Cin=3 stem goes through the zero-padded im2col matrix exactly as
+                 the device does (K padded to a multiple of 64)."""
+    if not exact:
+        cols, ho, wo = _im2col(x, L.kh, L.kw, L.stride, L.pad)
+        acc = cols @ L.w.reshape(L.cout, -1).T
+        return acc.reshape(x.shape[0], ho, wo, L.cout).astype(np.float32)
+    if L.cin % 64 == 0:
+        return conv_acc_exact(x, L.w, L.kh, L.kw, L.stride, L.pad)
     cols, ho, wo = _im2col(x, L.kh, L.kw, L.stride, L.pad)
-    acc = cols @ L.w.reshape(L.cout, -1).T
-    return acc.reshape(x.shape[0], ho, wo, L.cout).astype(np.float32)
+    k = cols.shape[1]
+    kpad = (k + 63) // 64 * 64
+    a1 = np.zeros((x.shape[0], ho, wo, kpad), np.float32)
+    a1[..., :k] = cols.reshape(x.shape[0], ho, wo, k)
+    wp = np.zeros((L.cout, 1, 1, kpad), np.float32)
+    wp[:, 0, 0, :k] = L.w.reshape(L.cout, k)
+    return conv_acc_exact(a1, wp, 1, 1, 1, 0)
 
 
 def epilogue(acc, bias, res=None, relu=True, keep=None, scale=np.float32(1.0)) -> np.ndarray:
@@ -254,8 +304,9 @@ def n_sites(arch: int) -> int:
 
 
 class OracleNet:
-    def __init__(self, model: Model):
+    def __init__(self, model: Model, exact: bool = False):
         self.m = model
+        self.exact = exact
         self.cfg = arch_cfg(model.arch)
         self.blocks = []
         idx = 1
@@ -271,7 +322,7 @@ class OracleNet:
 
     # -- stages -------------------------------------------------------------
     def stem(self, xn):
-        y = epilogue(conv_acc(xn, self.m.layers[0]), self.m.layers[0].b)
+        y = epilogue(conv_acc(xn, self.m.layers[0], self.exact), self.m.layers[0].b)
         if self.cfg["stem"] == "imagenet":
             y = maxpool3x3s2(y)
         return y
@@ -280,10 +331,10 @@ class OracleNet:
         main, down = self.blocks[i]
         h = x
         for L in main[:-1]:
-            h = epilogue(conv_acc(h, L), L.b)
-        idn = x if down is None else epilogue(conv_acc(x, down), down.b, relu=False)
+            h = epilogue(conv_acc(h, L, self.exact), L.b)
+        idn = x if down is None else epilogue(conv_acc(x, down, self.exact), down.b, relu=False)
         L = main[-1]
-        return epilogue(conv_acc(h, L), L.b, res=idn, keep=keep, scale=scale)
+        return epilogue(conv_acc(h, L, self.exact), L.b, res=idn, keep=keep, scale=scale)
 
     def pool(self, x, keep=None, scale=np.float32(1.0)):
         y = global_avgpool(x)
@@ -292,6 +343,9 @@ class OracleNet:
         return bf16_round(y)
 
     def logits(self, feat):
+        if self.exact:
+            acc = conv_acc_exact(feat[:, None, None, :], self.fc.w, 1, 1, 1, 0)[:, 0, 0, :]
+            return acc + self.fc.b
         return (feat @ self.fc.w.reshape(self.fc.cout, -1).T).astype(np.float32) + self.fc.b
 
     # -- full forward -------------------------------------------------------
@@ -400,6 +454,7 @@ class ClassifyConfig:
     temperature: float = 1.0
     conf_kind: int = CONF_MAX_SOFTMAX
     tau: float = 0.5
+    exact: bool = False   # reproduce the device's FAV_MATH_F32_EXACT mode bit for bit
 
 
 def inv_std32(std):
@@ -407,7 +462,7 @@ def inv_std32(std):
 
 
 def classify(model: Model, images: np.ndarray, cfg: ClassifyConfig, img_ids=None, return_logits=False):
-    net = OracleNet(model)
+    net = OracleNet(model, exact=cfg.exact)
     xn = normalize_input(images, cfg.mean, inv_std32(cfg.std))
     lg = net.forward_logits(xn, img_ids, cfg.n_samples, cfg.site_mask, cfg.p, cfg.seed)
     labels, conf, pbar = confidence_head(lg, cfg.temperature, cfg.conf_kind)

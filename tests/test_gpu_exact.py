@@ -1,0 +1,84 @@
+"""Bit-for-bit parity in FAV_MATH_F32_EXACT mode.
+
+In this mode the HIP kernel feeds the same bf16 operands, tiles and epilogue to the
+fp32-input MFMA, whose accumulation is a k-ordered fmaf chain; oracle/fav_exact.c
+restates that chain on the CPU.  Everything else on the path (normalisation, im2col,
+bias/residual/ReLU/dropout epilogue, pools, Philox masks) is order-free fp32 or
+integer arithmetic, so the LOGITS must be bit-identical and labels exactly equal, for
+every architecture, dropout policy and chunking.  The production bf16 mode differs
+from this mode only in the MFMA instruction issued (same operands, same k-tiles)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from failure_aware_vision_amd import Backend, _lib, synth, weights  # noqa: E402
+from oracle import fav_oracle as O  # noqa: E402
+from test_gpu_ops import run_conv  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,n", [
+    (64, 64, 1, 1, 0, 14, 14, 3), (64, 128, 3, 2, 1, 15, 15, 2), (128, 256, 3, 1, 1, 9, 9, 2),
+    (512, 128, 1, 1, 0, 7, 7, 3), (192, 64, 1, 1, 0, 16, 16, 2), (256, 512, 1, 2, 0, 14, 14, 1),
+])
+def test_conv_exact_bitwise(lib, cin, cout, k, stride, pad, H, W, n):
+    rng = np.random.default_rng(cin + cout + k)
+    x = O.bf16_round((rng.standard_normal((n, H, W, cin)) * np.exp2(rng.integers(-3, 4, (n, H, W, cin)))).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32))
+    b = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    acc = O.conv_acc_exact(x, w, k, k, stride, pad)
+    got = run_conv(lib, x, w, b, None, stride, pad, relu=0, out_f32=1, math_mode=1)
+    assert np.array_equal(got, acc + b)
+    res = O.bf16_round(rng.standard_normal(acc.shape).astype(np.float32))
+    got2 = run_conv(lib, x, w, b, res, stride, pad, relu=1, math_mode=1)
+    assert np.array_equal(got2, O.epilogue(acc, b, res=res, relu=True))
+
+
+def _exact_case(arch, blob, frames, first_index=0, hw=None, **kw):
+    model = O.parse_blob(blob)
+    aid = weights.ARCH_IDS[arch]
+    policy = kw.get("dropout_policy", "none")
+    T = kw.get("n_samples", 1)
+    be = Backend(arch, blob, max_batch=frames.shape[0], math_mode="f32_exact", in_hw=hw, **kw)
+    labels, conf = be.classify(torch.from_numpy(frames).cuda(), first_index=first_index)
+    lg = be.logits().cpu().numpy()
+    ocfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(aid, policy), p=kw.get("dropout_p", 0.0),
+                            seed=kw.get("seed", 0), exact=True,
+                            conf_kind=O.CONF_ENTROPY if kw.get("conf_kind") == "entropy" else O.CONF_MAX_SOFTMAX)
+    ids = np.arange(first_index, first_index + frames.shape[0])
+    ol, oc, olg, opb = O.classify(model, frames, ocfg, img_ids=ids, return_logits=True)
+    be.close()
+    assert lg.shape == olg.shape
+    assert np.array_equal(lg, olg), f"logits differ: {np.mean(lg != olg):.4f} of elements, max {np.abs(lg - olg).max()}"
+    srt = np.sort(opb, axis=1)
+    tie = (srt[:, -1] - srt[:, -2]) < 1e-6   # the head's expf may differ by an ulp from NumPy's
+    assert np.array_equal(labels.cpu().numpy()[~tie], ol[~tie])
+    np.testing.assert_allclose(conf.cpu().numpy(), oc, rtol=0, atol=3e-6)
+
+
+def test_resnet18_exact_single_pass(r18_blob):
+    _exact_case("resnet18_cifar", r18_blob[0], synth.synthetic_frames_u8(32, 32, 32, seed=7))
+
+
+@pytest.mark.parametrize("policy", ["last_layer", "layer4+fc", "all_blocks"])
+def test_resnet18_exact_mc_dropout(r18_blob, policy):
+    _exact_case("resnet18_cifar", r18_blob[0], synth.synthetic_frames_u8(10, 32, 32, seed=8), first_index=123,
+                n_samples=4, dropout_policy=policy, dropout_p=0.1, seed=4, conf_kind="entropy", chunk_a=7, chunk_b=9)
+
+
+def test_resnet50_exact_224(r50_blob):
+    frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(3, 224, 224, seed=7), 3, seed=3)
+    _exact_case("resnet50", r50_blob[0], frames)
+
+
+def test_resnet50_exact_mc_dropout_small(r50_blob):
+    frames = synth.synthetic_frames_u8(4, 96, 96, seed=9)
+    _exact_case("resnet50", r50_blob[0], frames, first_index=5, hw=(96, 96), n_samples=3, dropout_policy="all_blocks",
+                dropout_p=0.1, seed=4, chunk_a=3, chunk_b=5, regroup_block=9)
+    _exact_case("resnet50", r50_blob[0], frames, hw=(96, 96), n_samples=2, dropout_policy="layer4+fc", dropout_p=0.2, seed=11)
