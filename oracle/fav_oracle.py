@@ -368,22 +368,30 @@ class OracleNet:
                 keep = dropout_keep(seed, t, self.nb, img_ids, act.shape[-1], thr)
             return self.logits(self.pool(act, keep, scale))
 
-        # deterministic prefix: stem + blocks up to and including block `first`
-        # (its dropout is applied per sample on the cached, un-dropped output).
+        # deterministic prefix, computed once: stem + blocks up to and including block
+        # `first` (or through the pool when the first site is the pooled vector).  The
+        # first site's dropout is applied per sample to that cached, already bf16-rounded
+        # tensor ("entry dropout": x*scale re-rounded to bf16); later sites are fused
+        # into their producer's epilogue before its single rounding.
         act = self.stem(xn)
         if first > self.nb:  # no dropout at all
             return run_from(0, act, 0)[None]
         npre = min(first + 1, self.nb)  # blocks computed once
         for i in range(npre):
             act = self.block(i, act)
+        if first == self.nb:
+            act = self.pool(act)        # [B, C], rounded
+
+        def entry(a, t):
+            keep = dropout_keep(seed, t, first, img_ids, int(np.prod(a.shape[1:])), thr)
+            return bf16_round(np.where(keep.reshape(a.shape), a * scale, np.float32(0.0)).astype(np.float32))
+
         out = []
         for t in range(n_samples):
-            a = act
-            if first < self.nb:
-                keep = dropout_keep(seed, t, first, img_ids, int(np.prod(a.shape[1:])), thr)
-                # dropout of an already-rounded bf16 tensor: x*scale re-rounded to bf16
-                a = bf16_round(np.where(keep.reshape(a.shape), a * scale, np.float32(0.0)).astype(np.float32))
-            out.append(run_from(npre, a, t))
+            if first == self.nb:
+                out.append(self.logits(entry(act, t)))
+            else:
+                out.append(run_from(npre, entry(act, t), t))
         return np.stack(out)
 
     def _block_with_site(self, i, act, t, img_ids, site_mask, seed, thr, scale):

@@ -123,13 +123,22 @@ class TorchNet:
         npre = min(first + 1, self.nb)
         for i in range(npre):
             act = self.block(i, act)
+        zero = torch.zeros((), dtype=torch.float32)
+        if first == self.nb:  # entry dropout on the rounded pooled vector
+            b_, c_, h_, w_ = act.shape
+            acc = torch.zeros(b_, c_)
+            for i in range(h_):
+                for j in range(w_):
+                    acc = acc + act[:, :, i, j]
+            pooled = _bf16(acc * float(np.float32(1.0 / (h_ * w_))))
         outs = []
         for t in range(n_samples):
-            a = act
-            if first < self.nb:
-                keep = self._keep_nchw(seed, t, first, img_ids, tuple(a.shape), thr)
-                a = _bf16(torch.where(keep, a * scale, torch.zeros((), dtype=torch.float32)))
-            outs.append(run_from(npre, a, t))
+            if first == self.nb:
+                keep = torch.from_numpy(O.dropout_keep(seed, t, first, img_ids, pooled.shape[1], thr))
+                outs.append(F.linear(_bf16(torch.where(keep, pooled * scale, zero)), self.fc_w, self.fc_b))
+            else:
+                keep = self._keep_nchw(seed, t, first, img_ids, tuple(act.shape), thr)
+                outs.append(run_from(npre, _bf16(torch.where(keep, act * scale, zero)), t))
         return torch.stack(outs).numpy()
 
 

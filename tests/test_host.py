@@ -101,7 +101,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 blob, _ = weights.make_synthetic("resnet18_cifar", seed=1)
 model = O.parse_blob(blob)
-cfg = O.ClassifyConfig(n_samples=3, site_mask=weights.site_mask_for(0, "all_blocks"), p=0.1, seed=4)
+cfg = O.ClassifyConfig(n_samples=3, site_mask=weights.site_mask_for(0, "all_blocks"), p=0.1, seed=4,
+                       exact=True)   # fixed summation order: a frame's result cannot depend on its shard
 n = 11
 frames = synth.synthetic_frames_u8(n, 32, 32, seed=5)
 def stand_in(local, first_index=0):   # plays the per-rank Backend.classify
