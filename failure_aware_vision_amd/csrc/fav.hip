@@ -479,9 +479,11 @@ fav_status plan_memory(fav_handle* h) {
             const Op& o = h->ops[k];
             pe = std::max(pe, o.out == B_A1 ? o.out_elems / 2 : o.out_elems);
         }
-        // aim at ~40 MB per activation tensor so a block's live tensors sit in the 256 MiB L3,
-        // but never fewer rows than fill the CUs on the small late layers
-        const long long target = 40ll << 20;
+        // Pass size: measured on MI355X, fewer and larger launches beat keeping the
+        // producer->consumer tensors inside the 256 MiB Infinity Cache (launch gaps and
+        // the partial last wave of tiles cost more than the HBM round trip), so aim at
+        // ~800 MB per activation tensor; 288 GB of HBM makes the arena a non-issue.
+        const long long target = 800ll << 20;
         long long auto_chunk = std::max<long long>(1, target / (pe * 2));
         const int want = p.low_res ? c.chunk_b : c.chunk_a;
         long long chunk = want > 0 ? want : auto_chunk;

@@ -133,6 +133,26 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
 // ((acc + bias) + residual) -> ReLU -> dropout -> one bf16 rounding -> 16-B
 // coalesced stores.
 // ---------------------------------------------------------------------------
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS
+// at the wave-uniform address lds_dst.  Inline asm on purpose: hipcc orders a
+// builtin LDS-DMA against every later ds_read with s_waitcnt vmcnt(0), which
+// serialises the prefetch of tile k+1 with the MFMAs of tile k; an asm statement is
+// not counted, and the kernel retires it itself (vmcnt(0) + barrier before the
+// stage is read).  M0 carries the LDS address and is saved/restored in the same
+// statement (the compiler owns M0).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, const void* lds_dst) {
+    const uint32_t lds_addr =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+// 128 B of zeros: the source of padding taps and out-of-range rows for LDS-DMA
+__device__ uint4 g_zero_page[8];
+
 struct ConvParams {
     const uint16_t* x;
     const uint16_t* w;
@@ -181,59 +201,58 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread gather descriptors --------------------------------------
-    const int lc = tid & 7;   // 16-B chunk inside the 128-B K-tile row
-    const int lr = tid >> 3;  // 0..31
+    // ---- per-lane gather descriptors ------------------------------------------
+    // Tiles are staged with LDS-DMA (global_load_lds_dwordx4): one wave instruction
+    // writes 1 KiB = 8 rows x 128 B linearly into LDS, lane l -> row l>>3, 16-B slot
+    // l&7.  The bank-conflict swizzle therefore goes on the SOURCE: the lane that owns
+    // physical slot s of row r fetches logical chunk s ^ (r&7) (rows start at
+    // multiples of 8, so r&7 == l>>3), and fragment reads apply the same XOR.
+    // Padding taps and rows beyond M fetch from a zero page instead.
+    const int lrow = lane >> 3;
+    const int lch = (lane & 7) ^ lrow;
     long long a_base[AR];
     int a_ih0[AR], a_iw0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + lr + 32 * i;
+        const int m = m0 + wave * (AR * 8) + i * 8 + lrow;
         if (m < p.M) {
             const int vimg = m / p.HWo;
             const int pix = m - vimg * p.HWo;
             const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
             a_ih0[i] = oh * p.stride - p.pad;
             a_iw0[i] = ow * p.stride - p.pad;
-            a_base[i] = (long long)vimg * p.H * p.W * p.Cin + lc * 8;
+            a_base[i] = (long long)vimg * p.H * p.W * p.Cin + lch * 8;
         } else {
-            a_ih0[i] = -0x40000000;  // never in range -> zero fill
+            a_ih0[i] = -0x40000000;  // never in range -> zero page
             a_iw0[i] = 0;
             a_base[i] = 0;
         }
     }
-    const uint16_t* b_base = p.w + (long long)(n0 + lr) * p.K + lc * 8;
-    const long long b_step = 32ll * p.K;  // 32 weight rows further down
-
-    const int sw_off = (lc ^ (lr & 7)) << 4;  // swizzled chunk byte offset (row&7 == lr&7)
-    uint4 ra[AR], rb[BR];
+    const uint16_t* b_base = p.w + (long long)(n0 + wave * (BR * 8) + lrow) * p.K + lch * 8;
+    const long long b_step = 8ll * p.K;  // 8 weight rows further down
+    const uint16_t* zero_page = (const uint16_t*)g_zero_page;
     int tap_r = 0, tap_s = 0, c0 = 0;  // K-tile position: tap (r, s), channel offset
 
-// K-tile gather into registers / registers into the swizzled LDS stage.  Macros,
-// not lambdas: a by-reference closure kept the staging arrays in scratch memory.
-#define FAV_GLOAD(KT)                                                                             \
-    do {                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                          \
-            const int ih = a_ih0[i] + tap_r, iw = a_iw0[i] + tap_s;                               \
-            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)                     \
-                ra[i] = *(const uint4*)(p.x + a_base[i] + ((long long)ih * p.W + iw) * p.Cin + c0); \
-            else                                                                                  \
-                ra[i] = make_uint4(0, 0, 0, 0);                                                   \
-        }                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < BR; ++i)                                            \
-            rb[i] = *(const uint4*)(b_base + i * b_step + (KT) * BK);                             \
-        c0 += BK;                                                                                 \
-        if (c0 == p.Cin) {                                                                        \
-            c0 = 0;                                                                               \
-            if (++tap_s == p.kw) { tap_s = 0; ++tap_r; }                                          \
-        }                                                                                         \
-    } while (0)
-#define FAV_LSTORE(BUF)                                                                           \
-    do {                                                                                          \
-        unsigned char* As_ = smem + (BUF) * STAGE_BYTES;                                          \
-        unsigned char* Bs_ = As_ + A_BYTES;                                                       \
-        _Pragma("unroll") for (int i = 0; i < AR; ++i) *(uint4*)(As_ + (lr + 32 * i) * 128 + sw_off) = ra[i]; \
-        _Pragma("unroll") for (int i = 0; i < BR; ++i) *(uint4*)(Bs_ + (lr + 32 * i) * 128 + sw_off) = rb[i]; \
+// Issue the LDS-DMA of K tile KT into stage BUF (asynchronous; retired by the
+// explicit vmcnt(0) in front of the barrier that ends the K step).
+#define FAV_STAGE(BUF, KT)                                                                              \
+    do {                                                                                                \
+        unsigned char* As_ = smem + (BUF) * STAGE_BYTES + wave * (AR * 1024);                           \
+        unsigned char* Bs_ = smem + (BUF) * STAGE_BYTES + A_BYTES + wave * (BR * 1024);                 \
+        _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
+            const int ih = a_ih0[i] + tap_r, iw = a_iw0[i] + tap_s;                                     \
+            const uint16_t* src = zero_page;                                                            \
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)                           \
+                src = p.x + a_base[i] + ((long long)ih * p.W + iw) * p.Cin + c0;                        \
+            lds_dma16(src, As_ + i * 1024);                                                             \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                  \
+            lds_dma16(b_base + i * b_step + (KT) * BK, Bs_ + i * 1024);                                 \
+        c0 += BK;                                                                                       \
+        if (c0 == p.Cin) {                                                                              \
+            c0 = 0;                                                                                     \
+            if (++tap_s == p.kw) { tap_s = 0; ++tap_r; }                                                \
+        }                                                                                               \
     } while (0)
 
     f32x4_t acc[TN][TM];
@@ -245,15 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int frow = lane & 15;  // row of the 16-row fragment this lane reads
     const int fq = lane >> 4;    // which 8-element k chunk of a 32-wide k step
 
-    FAV_GLOAD(0);
-    FAV_LSTORE(0);
+    FAV_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = 0; kt < p.nk; ++kt) {
         const int cur = kt & 1;
-        // always prefetch (the last iteration re-reads the final tile; its result is
-        // never consumed) so the staging registers are defined on every path
-        FAV_GLOAD(kt + 1 < p.nk ? kt + 1 : p.nk - 1);
+        if (kt + 1 < p.nk) FAV_STAGE(cur ^ 1, kt + 1);
         const unsigned char* As = smem + cur * STAGE_BYTES;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                 }
             }
         }
-        FAV_LSTORE(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed
         __syncthreads();
     }
 
@@ -371,8 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
 }
 
-#undef FAV_GLOAD
-#undef FAV_LSTORE
+#undef FAV_STAGE
 
 // ---------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max pool, NHWC bf16; one thread = 8 channels of one output
