@@ -72,7 +72,7 @@ class Backend:
         if blob is None:
             blob, self.weights_info = _weights.make_synthetic(arch, seed=seed_weights, num_classes=cfg.num_classes)
         self.load_weights(blob)
-        self.mc = cfg.site_mask != 0 and round(cfg.dropout_p * 65536) > 0
+        self.mc = cfg.site_mask != 0 and round(cfg.dropout_p * 256) > 0
         self.T = cfg.n_samples if self.mc else 1
         self._prev_status_provider = None
 

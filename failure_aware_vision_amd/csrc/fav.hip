@@ -235,7 +235,7 @@ void launch_maxpool(fav_handle* h, const void* x, void* y, int n, int H, int W, 
 }
 
 void launch_avgpool(fav_handle* h, const void* x, void* y, int n, int HW, int C, const DropParams& dp, hipStream_t s) {
-    const long long total = (long long)n * (C / 8);
+    const long long total = (long long)n * (C / 16);
     Prof pr(h, s, FAV_K_AVGPOOL, 0.0, 2.0 * ((double)n * HW * C + (double)n * C));
     const float inv = 1.0f / (float)HW;
     hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)y, n, HW, C, inv,
@@ -244,10 +244,10 @@ void launch_avgpool(fav_handle* h, const void* x, void* y, int n, int HW, int C,
 
 void launch_entry_dropout(fav_handle* h, const void* x, void* out, long long elems, int n_out, const DropParams& dp,
                           hipStream_t s) {
-    const long long total = (elems / 8) * n_out;
+    const long long total = (elems / 16) * n_out;
     Prof pr(h, s, FAV_K_DROPOUT, 0.0, 4.0 * (double)elems * n_out);
     hipLaunchKernelGGL(entry_dropout_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)out,
-                       elems / 8, n_out, dp);
+                       elems / 16, n_out, dp);
 }
 
 const char* launch_head(fav_handle* h, const float* logits, int T, int n, int C, int ld, float temperature, int kind,
@@ -387,7 +387,7 @@ fav_status build_graph(fav_handle* h) {
     // ---- dropout sites and prefix / suffix split -----------------------------
     const uint32_t valid_mask = (h->nblocks + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (h->nblocks + 1)) - 1);
     if (c.site_mask & ~valid_mask) { h->err = "site_mask has bits beyond the pooled-feature site"; return FAV_ERR_INVALID_ARG; }
-    const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 65536.0);
+    const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 256.0);
     const bool mc = c.site_mask != 0 && thr > 0;
     h->T_eff = mc ? c.n_samples : 1;
     h->first_site = -1;
@@ -529,8 +529,8 @@ fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, i
     // a suffix phase that follows the prefix reads frame (v % n); later phases read virtual frame v
     const bool in_is_virtual = pi > 0 && h->phases[pi - 1].suffix;
     char* pout_base = (char*)h->phase_out[pi];
-    const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 65536.0);
-    const float scale = thr > 0 ? (float)(1.0 / (1.0 - thr / 65536.0)) : 1.0f;
+    const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 256.0);
+    const float scale = thr > 0 ? (float)(1.0 / (1.0 - thr / 256.0)) : 1.0f;
     float istd[3] = {1.0f / c.stdev[0], 1.0f / c.stdev[1], 1.0f / c.stdev[2]};
 
     for (long long v0 = 0; v0 < dom; v0 += p.chunk) {
@@ -861,13 +861,13 @@ fav_status fav_op_maxpool3x3s2(const void* x, void* y, int32_t n, int32_t H, int
 }
 
 fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t C, const fav_dropout_desc* drop, void* stream) {
-    if (!x || !y || C % 8 != 0 || HW < 1) return op_done("fav_op_avgpool: bad argument");
+    if (!x || !y || C % 16 != 0 || HW < 1) return op_done("fav_op_avgpool: bad argument");
     launch_avgpool(nullptr, x, y, n, HW, C, make_drop(drop), (hipStream_t)stream);
     return op_done(nullptr);
 }
 
 fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems, int32_t n_out, const fav_dropout_desc* drop, void* stream) {
-    if (!x || !out || !drop || drop->site < 0 || elems % 8 != 0) return op_done("fav_op_entry_dropout: bad argument");
+    if (!x || !out || !drop || drop->site < 0 || elems % 16 != 0) return op_done("fav_op_entry_dropout: bad argument");
     launch_entry_dropout(nullptr, x, out, elems, n_out, make_drop(drop), (hipStream_t)stream);
     return op_done(nullptr);
 }

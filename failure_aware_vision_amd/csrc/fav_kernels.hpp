@@ -25,8 +25,13 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     uint32_t u = __float_as_uint(f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
+// two fp32 -> packed bf16x2 with ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, the
+// same result as the integer recipe above for every finite input)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // Philox4x32-10 (Random123).  counter = (chunk, frame, sample, site), key = seed.
@@ -45,7 +50,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
 
 struct DropParams {
     int site;                 // -1: none
-    uint32_t thr;             // drop iff draw < thr
+    uint32_t thr;             // 8-bit threshold: drop iff draw < thr
     float scale;
     uint32_t seed_lo, seed_hi;
     long long v0;             // virtual frame index of row 0 (v = t * n_img + i)
@@ -53,20 +58,19 @@ struct DropParams {
     long long first_index;    // global index of frame 0
 };
 
-// 8-bit keep mask for the 8 elements of chunk `chunk` of virtual frame v
-__device__ __forceinline__ uint32_t drop_keep8(const DropParams& d, long long v, uint32_t chunk) {
+// 16-bit keep mask for the 16 elements of chunk `chunk` (= element_index / 16) of
+// virtual frame v: one Philox call = 16 bytes = 16 draws, byte j (little endian over
+// the four output words) belongs to element 16*chunk + j.
+__device__ __forceinline__ uint32_t drop_keep16(const DropParams& d, long long v, uint32_t chunk) {
     const uint32_t t = (uint32_t)(v / d.n_img);
     const uint32_t img = (uint32_t)(d.first_index + (v % d.n_img));
     const uint4 w = philox4x32_10(make_uint4(chunk, img, t, (uint32_t)d.site), d.seed_lo, d.seed_hi);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
     uint32_t m = 0;
-    m |= ((w.x & 0xFFFFu) >= d.thr) << 0;
-    m |= ((w.x >> 16) >= d.thr) << 1;
-    m |= ((w.y & 0xFFFFu) >= d.thr) << 2;
-    m |= ((w.y >> 16) >= d.thr) << 3;
-    m |= ((w.z & 0xFFFFu) >= d.thr) << 4;
-    m |= ((w.z >> 16) >= d.thr) << 5;
-    m |= ((w.w & 0xFFFFu) >= d.thr) << 6;
-    m |= ((w.w >> 16) >= d.thr) << 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m |= (uint32_t)(((ww[q] >> (8 * b)) & 0xFFu) >= d.thr) << (4 * q + b);
     return m;
 }
 
@@ -321,9 +325,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         __syncthreads();
     }
 
-    // ---- epilogue: stage fp32 tile through LDS -------------------------------
-    // (the barrier that ended the K loop already separates the last fragment
-    // reads from these writes)
+    // ---- epilogue ----------------------------------------------------------------
+    // A thread finishes 16 consecutive channels of one output pixel per pass (two 16-B
+    // stores; one Philox call covers exactly its 16 dropout draws).  Residual rows are
+    // requested BEFORE the accumulators go through LDS so their latency hides behind
+    // the staging barrier.  (The barrier that ended the K loop already separates the
+    // last fragment reads from the staging writes.)
+    constexpr int NCH = BN / 16;         // 16-channel chunks per row
+    constexpr int RPP = 256 / NCH;       // rows per pass
+    constexpr int NPASS = BM / RPP;
+    const int ec = tid % NCH, er = tid / NCH;
+    const int n = n0 + ec * 16;
+    uint4 rres[NPASS][2];
+    if (p.res) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int m = m0 + er + pass * RPP;
+            if (m < p.M && n < p.Cout) {
+                const uint4* rp = (const uint4*)(p.res + (long long)m * p.ldy + n);
+                rres[pass][0] = rp[0];
+                rres[pass][1] = rp[1];
+            }
+        }
+    }
     float* outs = (float*)smem;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -335,55 +359,57 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
     __syncthreads();
 
-    constexpr int NCH = BN / 8;          // 8-channel chunks per row
-    constexpr int RPP = 256 / NCH;       // rows per pass
-    const int ec = tid % NCH, er = tid / NCH;
-    const int n = n0 + ec * 8;
-    float bias8[8];
-    {
-        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-        bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    float bias16[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bq = *(const float4*)(p.bias + n + 4 * q);
+        bias16[4 * q] = bq.x; bias16[4 * q + 1] = bq.y; bias16[4 * q + 2] = bq.z; bias16[4 * q + 3] = bq.w;
     }
-#pragma unroll 2
-    for (int pass = 0; pass < BM / RPP; ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
         const int ml = er + pass * RPP;
         const int m = m0 + ml;
         if (m >= p.M || n >= p.Cout) continue;
-        const float4 v0 = *(const float4*)(outs + ml * OUT_LD + ec * 8);
-        const float4 v1 = *(const float4*)(outs + ml * OUT_LD + ec * 8 + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float v[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(v[j], bias8[j]);
+        for (int q = 0; q < 4; ++q) {
+            const float4 t4 = *(const float4*)(outs + ml * OUT_LD + ec * 16 + 4 * q);
+            v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __fadd_rn(v[j], bias16[j]);
         if (p.res) {
-            const uint4 r = *(const uint4*)(p.res + (long long)m * p.ldy + n);
-            const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+            const uint32_t rw[8] = {rres[pass][0].x, rres[pass][0].y, rres[pass][0].z, rres[pass][0].w,
+                                    rres[pass][1].x, rres[pass][1].y, rres[pass][1].z, rres[pass][1].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 v[2 * j] = __fadd_rn(v[2 * j], bf16_bits_to_f32(rw[j] & 0xFFFFu));
                 v[2 * j + 1] = __fadd_rn(v[2 * j + 1], bf16_bits_to_f32(rw[j] >> 16));
             }
         }
         if (p.relu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         if (p.out_f32) {
             float* yo = (float*)p.y + (long long)m * p.ldy + n;
-            *(float4*)yo = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + 4 * q < p.Cout) *(float4*)(yo + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         } else {
             if (p.drop.site >= 0) {
                 const int vl = m / p.HWo;
                 const int pix = m - vl * p.HWo;
-                const uint32_t chunk = (uint32_t)(((long long)pix * p.Cout + n) >> 3);
-                const uint32_t keep = drop_keep8(p.drop, p.drop.v0 + vl, chunk);
+                const uint32_t chunk = (uint32_t)(((long long)pix * p.Cout + n) >> 4);
+                const uint32_t keep = drop_keep16(p.drop, p.drop.v0 + vl, chunk);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ((keep >> j) & 1u) ? __fmul_rn(v[j], p.drop.scale) : 0.f;
+                for (int j = 0; j < 16; ++j) v[j] = ((keep >> j) & 1u) ? __fmul_rn(v[j], p.drop.scale) : 0.f;
             }
-            uint16_t* yo = (uint16_t*)p.y + (long long)m * p.ldy + n;
-            *(uint4*)yo = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                     pack_bf16x2(v[6], v[7]));
+            uint4* yo = (uint4*)((uint16_t*)p.y + (long long)m * p.ldy + n);
+            yo[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                               pack_bf16x2(v[6], v[7]));
+            yo[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]),
+                               pack_bf16x2(v[14], v[15]));
         }
     }
 }
@@ -434,31 +460,35 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint4* __restri
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int n,
                                                       int HW, int C, float inv_hw, DropParams drop) {
-    const int cch = C >> 3;
+    const int cch = C >> 4;  // 16-channel chunks = pairs of uint4
     const long long total = (long long)n * cch;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c = (int)(idx % cch);
         const long long img = idx / cch;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const uint4* src = x + img * HW * cch + c;
-        for (int i = 0; i < HW; ++i) {
-            const uint4 v = src[(long long)i * cch];
-            const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        float acc[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        const uint4* src = x + (img * HW * cch + c) * 2;
+        for (int i = 0; i < HW; ++i) {
+            const uint4 v0 = src[(long long)i * cch * 2], v1 = src[(long long)i * cch * 2 + 1];
+            const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 acc[2 * j] = __fadd_rn(acc[2 * j], bf16_bits_to_f32(vw[j] & 0xFFFFu));
                 acc[2 * j + 1] = __fadd_rn(acc[2 * j + 1], bf16_bits_to_f32(vw[j] >> 16));
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = __fmul_rn(acc[j], inv_hw);
+        for (int j = 0; j < 16; ++j) acc[j] = __fmul_rn(acc[j], inv_hw);
         if (drop.site >= 0) {
-            const uint32_t keep = drop_keep8(drop, drop.v0 + img, (uint32_t)c);
+            const uint32_t keep = drop_keep16(drop, drop.v0 + img, (uint32_t)c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = ((keep >> j) & 1u) ? __fmul_rn(acc[j], drop.scale) : 0.f;
+            for (int j = 0; j < 16; ++j) acc[j] = ((keep >> j) & 1u) ? __fmul_rn(acc[j], drop.scale) : 0.f;
         }
-        y[idx] = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
-                            pack_bf16x2(acc[6], acc[7]));
+        y[idx * 2] = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                                pack_bf16x2(acc[6], acc[7]));
+        y[idx * 2 + 1] = make_uint4(pack_bf16x2(acc[8], acc[9]), pack_bf16x2(acc[10], acc[11]),
+                                    pack_bf16x2(acc[12], acc[13]), pack_bf16x2(acc[14], acc[15]));
     }
 }
 
@@ -469,22 +499,25 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const uint4* __restrict__ 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void entry_dropout_kernel(const uint4* __restrict__ x, uint4* __restrict__ out,
                                                             long long chunks_per_frame, int n_out, DropParams drop) {
+    // chunk = 16 elements = two uint4
     const long long total = chunks_per_frame * n_out;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const long long vl = idx / chunks_per_frame;
         const uint32_t chunk = (uint32_t)(idx - vl * chunks_per_frame);
         const long long v = drop.v0 + vl;
-        const uint4 val = x[(v % drop.n_img) * chunks_per_frame + chunk];
-        const uint32_t keep = drop_keep8(drop, v, chunk);
-        const uint32_t vw[4] = {val.x, val.y, val.z, val.w};
-        uint32_t o[4];
+        const uint4* src = x + ((v % drop.n_img) * chunks_per_frame + chunk) * 2;
+        const uint4 a0 = src[0], a1 = src[1];
+        const uint32_t keep = drop_keep16(drop, v, chunk);
+        const uint32_t vw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        uint32_t o[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const float lo = ((keep >> (2 * j)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] & 0xFFFFu), drop.scale) : 0.f;
             const float hi = ((keep >> (2 * j + 1)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] >> 16), drop.scale) : 0.f;
             o[j] = pack_bf16x2(lo, hi);
         }
-        out[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+        out[idx * 2] = make_uint4(o[0], o[1], o[2], o[3]);
+        out[idx * 2 + 1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
 }
 

@@ -143,8 +143,8 @@ fav_status fav_get_profile(fav_handle* h, fav_profile* out, int32_t reset); /* s
  * per-kernel parity tests).  All tensors NHWC, bf16 unless noted. ---- */
 typedef struct fav_dropout_desc {
     int32_t site;            /* -1 = no dropout */
-    uint32_t threshold;      /* drop iff 16-bit draw < threshold */
-    float scale;             /* 1 / (1 - threshold/65536) */
+    uint32_t threshold;      /* drop iff 8-bit draw < threshold (= round(p * 256)) */
+    float scale;             /* 1 / (1 - threshold/256) */
     uint64_t seed;
     int64_t v0;              /* virtual frame index of row 0: v = t * n_img + i */
     int32_t n_img;           /* frames per sample */

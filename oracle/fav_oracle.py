@@ -32,8 +32,9 @@ Numerical contract (mirrored by the HIP path):
   fp32(1/HW), rounded to bf16;
 * logits stay fp32; softmax, mean over samples, entropy are fp32;
 * dropout masks: Philox4x32-10, key=(seed_lo, seed_hi),
-  counter=(element_index//8, global_image_index, sample t, site); the four
-  output words give eight 16-bit draws (low half first); keep iff draw >= thr.
+  counter=(element_index//16, global_image_index, sample t, site); the four
+  output words give sixteen 8-bit draws (little endian); keep iff draw >= thr,
+  thr = round(p*256), survivors scaled by fp32(1/(1 - thr/256)).
 """
 from __future__ import annotations
 
@@ -94,25 +95,26 @@ def philox4x32_10(c0, c1, c2, c3, k0: int, k1: int):
 
 
 def dropout_threshold(p: float) -> int:
-    """16-bit drop threshold: an element is dropped iff its draw < thr."""
-    return int(round(float(p) * 65536.0))
+    """8-bit drop threshold: an element is dropped iff its draw < thr."""
+    return int(round(float(p) * 256.0))
 
 
 def dropout_scale(thr: int) -> np.float32:
-    return np.float32(1.0 / (1.0 - thr / 65536.0)) if thr > 0 else np.float32(1.0)
+    return np.float32(1.0 / (1.0 - thr / 256.0)) if thr > 0 else np.float32(1.0)
 
 
 def dropout_keep(seed: int, t: int, site: int, img_ids: np.ndarray, n_elem: int, thr: int) -> np.ndarray:
-    """Boolean keep mask [len(img_ids), n_elem] (n_elem multiple of 8)."""
-    assert n_elem % 8 == 0
-    chunks = np.arange(n_elem // 8, dtype=np.uint32)[None, :]
+    """Boolean keep mask [len(img_ids), n_elem] (n_elem multiple of 16).  One Philox
+    call per 16 elements: byte j (little endian over the four words) is element j's draw."""
+    assert n_elem % 16 == 0
+    chunks = np.arange(n_elem // 16, dtype=np.uint32)[None, :]
     imgs = np.asarray(img_ids, dtype=np.uint32)[:, None]
     w = philox4x32_10(chunks, imgs, np.uint32(t), np.uint32(site),
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    draws = np.empty((imgs.shape[0], n_elem // 8, 8), dtype=np.uint32)
-    for j in range(4):
-        draws[:, :, 2 * j] = w[j] & np.uint32(0xFFFF)
-        draws[:, :, 2 * j + 1] = w[j] >> np.uint32(16)
+    draws = np.empty((imgs.shape[0], n_elem // 16, 16), dtype=np.uint32)
+    for q in range(4):
+        for b in range(4):
+            draws[:, :, 4 * q + b] = (w[q] >> np.uint32(8 * b)) & np.uint32(0xFF)
     return (draws >= np.uint32(thr)).reshape(imgs.shape[0], n_elem)
 
 
