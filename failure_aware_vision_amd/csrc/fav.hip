@@ -189,6 +189,12 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
     const int BM = 128;
     const int BN = (cout_pad % 128 == 0) ? 128 : 64;
+    {   // LDS-DMA offsets are 32-bit from the tile's first frame; out-of-range lanes use 0x80000000
+        const double frame_bytes = 2.0 * d.H * d.W * d.Cin;
+        const double span = (BM / (double)p.HWo + 2.0) * frame_bytes + 2.0 * ((double)d.pad * d.W + d.pad) * d.Cin +
+                            2.0 * (((double)d.kh * d.W + d.kw) * d.Cin);
+        if (span >= 2147483647.0 || 2.0 * BN * (double)p.K >= 2147483647.0) return "conv: frame too large for 32-bit tile offsets";
+    }
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = cout_pad / BN;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;

@@ -137,25 +137,22 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
 // ((acc + bias) + residual) -> ReLU -> dropout -> one bf16 rounding -> 16-B
 // coalesced stores.
 // ---------------------------------------------------------------------------
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS
-// at the wave-uniform address lds_dst.  Inline asm on purpose: hipcc orders a
+// One LDS-DMA piece: buffer_load_dwordx4 ... lds moves 64 lanes x 16 B from
+// (descriptor base + per-lane voffset + uniform soffset) to 1 KiB of LDS at the
+// wave-uniform address in M0.  A lane whose voffset fails the descriptor's range
+// check (we use 0x80000000 for padding taps and rows beyond M) contributes zeros,
+// which is exactly the im2col zero padding.  Inline asm on purpose: hipcc orders a
 // builtin LDS-DMA against every later ds_read with s_waitcnt vmcnt(0), which
 // serialises the prefetch of tile k+1 with the MFMAs of tile k; an asm statement is
 // not counted, and the kernel retires it itself (vmcnt(0) + barrier before the
-// stage is read).  M0 carries the LDS address and is saved/restored in the same
-// statement (the compiler owns M0).
-__device__ __forceinline__ void lds_dma16(const void* gsrc, const void* lds_dst) {
-    const uint32_t lds_addr =
-        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst);
+// stage is read).  M0 is saved/restored in the same statement (the compiler owns it).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t srd, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
+                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
                  : "memory");
 }
-
-// 128 B of zeros: the source of padding taps and out-of-range rows for LDS-DMA
-__device__ uint4 g_zero_page[8];
 
 struct ConvParams {
     const uint16_t* x;
@@ -206,15 +203,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-lane gather descriptors ------------------------------------------
-    // Tiles are staged with LDS-DMA (global_load_lds_dwordx4): one wave instruction
-    // writes 1 KiB = 8 rows x 128 B linearly into LDS, lane l -> row l>>3, 16-B slot
-    // l&7.  The bank-conflict swizzle therefore goes on the SOURCE: the lane that owns
-    // physical slot s of row r fetches logical chunk s ^ (r&7) (rows start at
-    // multiples of 8, so r&7 == l>>3), and fragment reads apply the same XOR.
-    // Padding taps and rows beyond M fetch from a zero page instead.
+    // Tiles are staged with LDS-DMA: one wave instruction writes 1 KiB = 8 rows x
+    // 128 B linearly into LDS, lane l -> row l>>3, 16-B slot l&7.  The bank-conflict
+    // swizzle therefore goes on the SOURCE: the lane that owns physical slot s of row
+    // r fetches logical chunk s ^ (r&7) (rows start at multiples of 8, so r&7 ==
+    // l>>3), and fragment reads apply the same XOR.
+    //
+    // Addressing is split so the K loop does almost no vector arithmetic:
+    //   address = [descriptor base: first frame of the tile, shifted back by the
+    //              padding so every offset is >= 0]                      (uniform)
+    //           + voffset: this lane's row (frame, oh*stride, ow*stride, chunk)  (per lane, fixed)
+    //           + soffset: the K tile's tap (r, s) and channel offset     (uniform, per tile)
+    // and a padding tap / row beyond M just swaps voffset for an out-of-range value.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int lrow = lane >> 3;
     const int lch = (lane & 7) ^ lrow;
-    long long a_base[AR];
+    const long long frame_elems = (long long)p.H * p.W * p.Cin;
+    const int vimg0 = m0 / p.HWo;
+    const int pad_shift = (p.pad * p.W + p.pad) * p.Cin;
+    const __amdgpu_buffer_rsrc_t srd_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + vimg0 * frame_elems - pad_shift), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_b =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * p.K), 0, BN * p.K * 2, 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+    uint32_t a_voff[AR];
     int a_ih0[AR], a_iw0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -225,33 +237,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
             a_ih0[i] = oh * p.stride - p.pad;
             a_iw0[i] = ow * p.stride - p.pad;
-            a_base[i] = (long long)vimg * p.H * p.W * p.Cin + lch * 8;
+            a_voff[i] = (uint32_t)(((long long)(vimg - vimg0) * frame_elems +
+                                    (long long)(a_ih0[i] * p.W + a_iw0[i]) * p.Cin + pad_shift + lch * 8) * 2);
         } else {
-            a_ih0[i] = -0x40000000;  // never in range -> zero page
+            a_ih0[i] = -0x40000000;  // never in range
             a_iw0[i] = 0;
-            a_base[i] = 0;
+            a_voff[i] = OOB;
         }
     }
-    const uint16_t* b_base = p.w + (long long)(n0 + wave * (BR * 8) + lrow) * p.K + lch * 8;
-    const long long b_step = 8ll * p.K;  // 8 weight rows further down
-    const uint16_t* zero_page = (const uint16_t*)g_zero_page;
+    uint32_t b_voff[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)(((wave * (BR * 8) + i * 8 + lrow) * p.K + lch * 8) * 2);
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)smem);
+    const uint32_t lds_a = lds_base + wave_u * (AR * 1024);
+    const uint32_t lds_b = lds_base + A_BYTES + wave_u * (BR * 1024);
     int tap_r = 0, tap_s = 0, c0 = 0;  // K-tile position: tap (r, s), channel offset
 
 // Issue the LDS-DMA of K tile KT into stage BUF (asynchronous; retired by the
 // explicit vmcnt(0) in front of the barrier that ends the K step).
 #define FAV_STAGE(BUF, KT)                                                                              \
     do {                                                                                                \
-        unsigned char* As_ = smem + (BUF) * STAGE_BYTES + wave * (AR * 1024);                           \
-        unsigned char* Bs_ = smem + (BUF) * STAGE_BYTES + A_BYTES + wave * (BR * 1024);                 \
+        const uint32_t soff_a = (uint32_t)(((tap_r * p.W + tap_s) * p.Cin + c0) * 2);                   \
         _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
-            const int ih = a_ih0[i] + tap_r, iw = a_iw0[i] + tap_s;                                     \
-            const uint16_t* src = zero_page;                                                            \
-            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)                           \
-                src = p.x + a_base[i] + ((long long)ih * p.W + iw) * p.Cin + c0;                        \
-            lds_dma16(src, As_ + i * 1024);                                                             \
+            const bool ok = (unsigned)(a_ih0[i] + tap_r) < (unsigned)p.H &&                             \
+                            (unsigned)(a_iw0[i] + tap_s) < (unsigned)p.W;                               \
+            lds_dma16(srd_a, ok ? a_voff[i] : OOB, soff_a, lds_a + (BUF) * STAGE_BYTES + i * 1024);     \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                  \
-            lds_dma16(b_base + i * b_step + (KT) * BK, Bs_ + i * 1024);                                 \
+            lds_dma16(srd_b, b_voff[i], (uint32_t)((KT) * (BK * 2)), lds_b + (BUF) * STAGE_BYTES + i * 1024); \
         c0 += BK;                                                                                       \
         if (c0 == p.Cin) {                                                                              \
             c0 = 0;                                                                                     \
