@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -169,6 +170,17 @@ DropParams make_drop(const fav_dropout_desc* d) {
     return p;
 }
 
+// K-tile depth.  Measured on MI355X (profiles/op_table_r1.txt): the 1x1 convolutions
+// are bound by HBM and by their epilogue, and run faster with 32-deep tiles (34 KB of
+// LDS -> 4 blocks per CU hide the latency); the 3x3 convolutions are MFMA-bound and
+// run faster with 64-deep tiles (half the barriers per FLOP).  FAV_CONV_BK=32|64
+// forces one depth for experiments.
+int conv_bk(int kh, int kw) {
+    static int forced = [] { const char* e = getenv("FAV_CONV_BK"); return e ? atoi(e) : 0; }();
+    if (forced == 32 || forced == 64) return forced;
+    return (kh * kw > 1) ? 64 : 32;
+}
+
 const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int ldy, hipStream_t s) {
     if (d.Cin % 64 != 0) return "conv: Cin must be a multiple of 64";
     if (cout_pad % 64 != 0) return "conv: padded Cout must be a multiple of 64";
@@ -204,13 +216,17 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
                                 + (double)d.Cout * p.K);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
     dim3 grid((unsigned)tiles), block(256);
+    const int BK = conv_bk(d.kh, d.kw);
+    p.nk = p.K / BK;
+#define FAV_LAUNCH(BN_, BK_, MODE_) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, MODE_>), grid, block, 0, s, p)
     if (d.math_mode == FAV_MATH_BF16) {
-        if (BN == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 0>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 0>), grid, block, 0, s, p);
+        if (BN == 128) { if (BK == 32) FAV_LAUNCH(128, 32, 0); else FAV_LAUNCH(128, 64, 0); }
+        else           { if (BK == 32) FAV_LAUNCH(64, 32, 0);  else FAV_LAUNCH(64, 64, 0); }
     } else {
-        if (BN == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 1>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 1>), grid, block, 0, s, p);
+        if (BN == 128) { if (BK == 32) FAV_LAUNCH(128, 32, 1); else FAV_LAUNCH(128, 64, 1); }
+        else           { if (BK == 32) FAV_LAUNCH(64, 32, 1);  else FAV_LAUNCH(64, 64, 1); }
     }
+#undef FAV_LAUNCH
     return nullptr;
 }
 
@@ -485,11 +501,12 @@ fav_status plan_memory(fav_handle* h) {
             const Op& o = h->ops[k];
             pe = std::max(pe, o.out == B_A1 ? o.out_elems / 2 : o.out_elems);
         }
-        // Pass size: measured on MI355X, fewer and larger launches beat keeping the
-        // producer->consumer tensors inside the 256 MiB Infinity Cache (launch gaps and
-        // the partial last wave of tiles cost more than the HBM round trip), so aim at
-        // ~800 MB per activation tensor; 288 GB of HBM makes the arena a non-issue.
-        const long long target = 800ll << 20;
+        // Pass size: measured on MI355X, fewer and larger launches beat
+        // keeping producer->consumer tensors inside the 256 MiB Infinity Cache at every
+        // size tried (launch ramp/tail cost more than the HBM round trip), so by default a
+        // phase runs all its frames in one pass, bounded by a 16 GiB-per-tensor arena
+        // budget (5 rotating tensors; 288 GB of HBM makes that a non-issue).
+        const long long target = 16ll << 30;
         long long auto_chunk = std::max<long long>(1, target / (pe * 2));
         const int want = p.low_res ? c.chunk_b : c.chunk_a;
         long long chunk = want > 0 ? want : auto_chunk;

@@ -165,23 +165,36 @@ struct ConvParams {
     int ldy;        // output row stride in elements
     int kw, stride, pad;
     int M;          // n_frames * Ho * Wo
-    int K, nk;      // K = kh*kw*Cin, nk = K / 64
+    int K, nk;      // K = kh*kw*Cin, nk = K / BK
     int relu, out_f32;
     int tiles_m, tiles_n;
     DropParams drop;
 };
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
-    constexpr int BK = 64;
+// LDS swizzle of a staged K tile: rows are BK*2 bytes, a row holds BK/8 16-B chunks.
+// Physical chunk = logical chunk ^ swz(row), chosen so the four 16-lane groups a
+// ds_read_b128 is served in ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) hit 16
+// distinct 16-B slots of the 256-B bank row:
+//   BK = 64 (128-B rows, 2 rows per bank row): swz = row & 7
+//   BK = 32 ( 64-B rows, 4 rows per bank row): swz = (-(row >> 2)) & 3
+template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+    return BK == 64 ? (row & 7) : ((-(row >> 2)) & 3);
+}
+
+template <int BM, int BN, int BK, int MODE>
+__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int ROWB = BK * 2;                // bytes per staged row
+    constexpr int CPR = BK / 8;                 // 16-B chunks per row
+    constexpr int PROWS = 1024 / ROWB;          // rows per 1-KiB LDS-DMA piece
     constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16; // 16x16 MFMA tiles per wave
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int OUT_LD = BN + 4;              // fp32 staging row stride (floats)
-    constexpr int OUT_BYTES = BM * OUT_LD * 4;
+    constexpr int OUT_BYTES = (BM / 2) * OUT_LD * 4;  // the epilogue stages half a tile at a time
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > OUT_BYTES) ? 2 * STAGE_BYTES : OUT_BYTES;
-    constexpr int AR = BM / 32, BR = BN / 32;   // rows per thread per tile
+    constexpr int AR = A_BYTES / 4096, BR = B_BYTES / 4096;  // LDS-DMA pieces per wave per tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -203,11 +216,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-lane gather descriptors ------------------------------------------
-    // Tiles are staged with LDS-DMA: one wave instruction writes 1 KiB = 8 rows x
-    // 128 B linearly into LDS, lane l -> row l>>3, 16-B slot l&7.  The bank-conflict
-    // swizzle therefore goes on the SOURCE: the lane that owns physical slot s of row
-    // r fetches logical chunk s ^ (r&7) (rows start at multiples of 8, so r&7 ==
-    // l>>3), and fragment reads apply the same XOR.
+    // Tiles are staged with LDS-DMA: one wave instruction writes 1 KiB = PROWS rows x
+    // ROWB bytes linearly into LDS, lane l -> row l / CPR, 16-B slot l % CPR.  The
+    // bank-conflict swizzle therefore goes on the SOURCE: the lane that owns physical
+    // slot s of row r fetches logical chunk s ^ swz(r) (pieces start at multiples of
+    // PROWS rows, so swz(r) depends on the lane only), and fragment reads apply the
+    // same XOR.
     //
     // Addressing is split so the K loop does almost no vector arithmetic:
     //   address = [descriptor base: first frame of the tile, shifted back by the
@@ -216,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     //           + soffset: the K tile's tap (r, s) and channel offset     (uniform, per tile)
     // and a padding tap / row beyond M just swaps voffset for an out-of-range value.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int lrow = lane >> 3;
-    const int lch = (lane & 7) ^ lrow;
+    const int lrow = lane / CPR;
+    const int lch = (lane % CPR) ^ lds_swz<BK>(lrow);
     const long long frame_elems = (long long)p.H * p.W * p.Cin;
     const int vimg0 = m0 / p.HWo;
     const int pad_shift = (p.pad * p.W + p.pad) * p.Cin;
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     int a_ih0[AR], a_iw0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + wave * (AR * 8) + i * 8 + lrow;
+        const int m = m0 + (wave * AR + i) * PROWS + lrow;
         if (m < p.M) {
             const int vimg = m / p.HWo;
             const int pix = m - vimg * p.HWo;
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
     uint32_t b_voff[BR];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)(((wave * (BR * 8) + i * 8 + lrow) * p.K + lch * 8) * 2);
+    for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)((((wave * BR + i) * PROWS + lrow) * p.K + lch * 8) * 2);
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)smem);
     const uint32_t lds_a = lds_base + wave_u * (AR * 1024);
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             lds_dma16(srd_a, ok ? a_voff[i] : OOB, soff_a, lds_a + (BUF) * STAGE_BYTES + i * 1024);     \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                  \
-            lds_dma16(srd_b, b_voff[i], (uint32_t)((KT) * (BK * 2)), lds_b + (BUF) * STAGE_BYTES + i * 1024); \
+            lds_dma16(srd_b, b_voff[i], (uint32_t)((KT) * ROWB), lds_b + (BUF) * STAGE_BYTES + i * 1024); \
         c0 += BK;                                                                                       \
         if (c0 == p.Cin) {                                                                              \
             c0 = 0;                                                                                     \
@@ -292,18 +306,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         const unsigned char* As = smem + cur * STAGE_BYTES;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             uint4 fx[TM], fw[TN];
             const int ch = kk * 4 + fq;
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int row = wm * WTM + b * 16 + frow;
-                fx[b] = *(const uint4*)(As + row * 128 + ((ch ^ (row & 7)) << 4));
+                fx[b] = *(const uint4*)(As + row * ROWB + ((ch ^ lds_swz<BK>(row)) << 4));
             }
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int row = wn * WTN + a * 16 + frow;
-                fw[a] = *(const uint4*)(Bs + row * 128 + ((ch ^ (row & 7)) << 4));
+                fw[a] = *(const uint4*)(Bs + row * ROWB + ((ch ^ lds_swz<BK>(row)) << 4));
             }
             if (MODE == 0) {
 #pragma unroll
@@ -340,90 +354,97 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
 
     // ---- epilogue ----------------------------------------------------------------
-    // A thread finishes 16 consecutive channels of one output pixel per pass (two 16-B
-    // stores; one Philox call covers exactly its 16 dropout draws).  Residual rows are
-    // requested BEFORE the accumulators go through LDS so their latency hides behind
-    // the staging barrier.  (The barrier that ended the K loop already separates the
-    // last fragment reads from the staging writes.)
-    constexpr int NCH = BN / 16;         // 16-channel chunks per row
-    constexpr int RPP = 256 / NCH;       // rows per pass
-    constexpr int NPASS = BM / RPP;
+    // Half a tile (BM/2 rows = the rows of one wave row wm) goes through LDS at a time
+    // so the staging area stays under the K-loop stages (more blocks per CU).  A thread
+    // finishes 16 consecutive channels of one output pixel per pass (two 16-B stores;
+    // one Philox call covers exactly its 16 dropout draws).  Residual rows are requested
+    // BEFORE the accumulators go through LDS so their latency hides behind the staging
+    // barrier.  (The barrier that ended the K loop already separates the last fragment
+    // reads from the first staging writes.)
+    constexpr int NCH = BN / 16;           // 16-channel chunks per row
+    constexpr int RPP = 256 / NCH;         // rows per pass
+    constexpr int NPASS = (BM / 2) / RPP;  // passes per half tile
     const int ec = tid % NCH, er = tid / NCH;
     const int n = n0 + ec * 16;
-    uint4 rres[NPASS][2];
-    if (p.res) {
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int m = m0 + er + pass * RPP;
-            if (m < p.M && n < p.Cout) {
-                const uint4* rp = (const uint4*)(p.res + (long long)m * p.ldy + n);
-                rres[pass][0] = rp[0];
-                rres[pass][1] = rp[1];
-            }
-        }
-    }
     float* outs = (float*)smem;
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const int ml = wm * WTM + b * 16 + frow;
-            const int nl = wn * WTN + a * 16 + fq * 4;
-            *(f32x4_t*)(outs + ml * OUT_LD + nl) = acc[a][b];
-        }
-    __syncthreads();
-
-    float bias16[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 bq = *(const float4*)(p.bias + n + 4 * q);
-        bias16[4 * q] = bq.x; bias16[4 * q + 1] = bq.y; bias16[4 * q + 2] = bq.z; bias16[4 * q + 3] = bq.w;
-    }
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int ml = er + pass * RPP;
-        const int m = m0 + ml;
-        if (m >= p.M || n >= p.Cout) continue;
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t4 = *(const float4*)(outs + ml * OUT_LD + ec * 16 + 4 * q);
-            v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __fadd_rn(v[j], bias16[j]);
+    for (int half = 0; half < 2; ++half) {
+        uint4 rres[NPASS][2];
         if (p.res) {
-            const uint32_t rw[8] = {rres[pass][0].x, rres[pass][0].y, rres[pass][0].z, rres[pass][0].w,
-                                    rres[pass][1].x, rres[pass][1].y, rres[pass][1].z, rres[pass][1].w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[2 * j] = __fadd_rn(v[2 * j], bf16_bits_to_f32(rw[j] & 0xFFFFu));
-                v[2 * j + 1] = __fadd_rn(v[2 * j + 1], bf16_bits_to_f32(rw[j] >> 16));
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m = m0 + half * (BM / 2) + er + pass * RPP;
+                if (m < p.M && n < p.Cout) {
+                    const uint4* rp = (const uint4*)(p.res + (long long)m * p.ldy + n);
+                    rres[pass][0] = rp[0];
+                    rres[pass][1] = rp[1];
+                }
             }
         }
-        if (p.relu) {
+        if (half == 1) __syncthreads();  // everyone is done reading the first half
+        if (wm == half) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int ml = b * 16 + frow;  // row inside the half tile
+                    const int nl = wn * WTN + a * 16 + fq * 4;
+                    *(f32x4_t*)(outs + ml * OUT_LD + nl) = acc[a][b];
+                }
         }
-        if (p.out_f32) {
-            float* yo = (float*)p.y + (long long)m * p.ldy + n;
+        __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (n + 4 * q < p.Cout) *(float4*)(yo + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        } else {
-            if (p.drop.site >= 0) {
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int ml = er + pass * RPP;
+            const int m = m0 + half * (BM / 2) + ml;
+            if (m >= p.M || n >= p.Cout) continue;
+            uint32_t keep = 0xFFFFu;
+            if (!p.out_f32 && p.drop.site >= 0) {
                 const int vl = m / p.HWo;
                 const int pix = m - vl * p.HWo;
                 const uint32_t chunk = (uint32_t)(((long long)pix * p.Cout + n) >> 4);
-                const uint32_t keep = drop_keep16(p.drop, p.drop.v0 + vl, chunk);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ((keep >> j) & 1u) ? __fmul_rn(v[j], p.drop.scale) : 0.f;
+                keep = drop_keep16(p.drop, p.drop.v0 + vl, chunk);
             }
-            uint4* yo = (uint4*)((uint16_t*)p.y + (long long)m * p.ldy + n);
-            yo[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                               pack_bf16x2(v[6], v[7]));
-            yo[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]),
-                               pack_bf16x2(v[14], v[15]));
+            // the 16 channels in two groups of 8 (keeps the live register set small)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 t4 = *(const float4*)(outs + ml * OUT_LD + ec * 16 + 8 * g + 4 * q);
+                    const float4 bq = *(const float4*)(p.bias + n + 8 * g + 4 * q);
+                    v[4 * q] = __fadd_rn(t4.x, bq.x); v[4 * q + 1] = __fadd_rn(t4.y, bq.y);
+                    v[4 * q + 2] = __fadd_rn(t4.z, bq.z); v[4 * q + 3] = __fadd_rn(t4.w, bq.w);
+                }
+                if (p.res) {
+                    const uint32_t rw[4] = {rres[pass][g].x, rres[pass][g].y, rres[pass][g].z, rres[pass][g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[2 * j] = __fadd_rn(v[2 * j], bf16_bits_to_f32(rw[j] & 0xFFFFu));
+                        v[2 * j + 1] = __fadd_rn(v[2 * j + 1], bf16_bits_to_f32(rw[j] >> 16));
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (p.out_f32) {
+                    float* yo = (float*)p.y + (long long)m * p.ldy + n + 8 * g;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (n + 8 * g + 4 * q < p.Cout)
+                            *(float4*)(yo + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                } else {
+                    if (p.drop.site >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            v[j] = ((keep >> (8 * g + j)) & 1u) ? __fmul_rn(v[j], p.drop.scale) : 0.f;
+                    }
+                    *(uint4*)((uint16_t*)p.y + (long long)m * p.ldy + n + 8 * g) =
+                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                   pack_bf16x2(v[6], v[7]));
+                }
+            }
         }
     }
 }

@@ -1,0 +1,30 @@
+"""Summarise rocprofv3 output directories produced by tools/profile.sh."""
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+
+def find(sub, pat):
+    r = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return r[0] if r else None
+
+f = find("trace", "*kernel_stats.csv")
+if f:
+    print("== kernel stats (rocprofv3 --kernel-trace --stats):", f)
+    for row in csv.DictReader(open(f)):
+        print("  %-90s calls %7s total_ms %10.3f avg_us %9.2f pct %6s" % (
+            row.get("Name", "")[:90], row.get("Calls"), float(row.get("TotalDurationNs", 0)) / 1e6,
+            float(row.get("AverageNs", 0)) / 1e3, row.get("Percentage")))
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        print("no counter csv for", sub); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.Counter()
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"][:60]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        n[(k, row["Counter_Name"])] += 1
+    print("== counters", sub)
+    for k, d in agg.items():
+        print("  ", k)
+        for c, v in d.items():
+            print("      %-28s sum %.4g  per-dispatch %.4g  (n=%d)" % (c, v, v / n[(k, c)], n[(k, c)]))
