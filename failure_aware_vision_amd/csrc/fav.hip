@@ -98,6 +98,15 @@ struct fav_handle {
     // workspace
     void* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t act_bytes = 0;
+    // two-stream pipeline over the last two phases: the low-resolution,
+    // MFMA-bound phase of chunk c runs on stream_b while the high-resolution, HBM-bound
+    // phase of chunk c+1 runs on stream_a.  The second phase has its own rotating set.
+    void* act2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t act2_bytes = 0;
+    int pipe_first = -1;            // index of the first phase of the pipelined pair (-1: none)
+    hipStream_t stream_a = nullptr, stream_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join_a = nullptr, ev_join_b = nullptr;
+    std::vector<hipEvent_t> ev_chunk;
     void* a1 = nullptr;
     size_t a1_bytes = 0;
     std::vector<void*> phase_out;   // output tensor of each phase
@@ -181,6 +190,36 @@ int conv_bk(int kh, int kw) {
     return (kh * kw > 1) ? 64 : 32;
 }
 
+// LDS stages of the K ring (2 = double buffer).  FAV_CONV_NS=2|3|4 forces.
+int conv_ns(int bk) {
+    static int forced = [] { const char* e = getenv("FAV_CONV_NS"); return e ? atoi(e) : 0; }();
+    if (forced >= 2 && forced <= 4) return (bk == 64 && forced == 4) ? 3 : forced;
+    return 2;
+}
+
+// M-tile height: 256-row tiles (8 waves, 96 KB of LDS, one block per CU) raise the
+// FLOPs per byte staged from L2 for the MFMA-bound 3x3 convolutions; everything else
+// uses 128 rows.  256-row tiles always use 64-deep K tiles.  FAV_CONV_BM=128|256 forces.
+int conv_bm(int kh, int kw, long long M) {
+    static int forced = [] { const char* e = getenv("FAV_CONV_BM"); return e ? atoi(e) : 0; }();
+    (void)forced;
+    (void)kh; (void)kw; (void)M;
+    return 128;  // measured: 256-row tiles (1 block/CU) lose to 2 blocks/CU of 128-row tiles on every 3x3 shape
+}
+
+// 256 x 256 x 64 tile (8 waves, 128 KB of LDS, one block per CU): twice the FLOPs per
+// byte staged from L2, which is what bounds the MFMA-heavy shapes.
+// Measured on MI355X it wins on the 3x3 convolutions and on the residual-free 1x1
+// convolutions with K >= 512 (+6..25 %), and loses wherever the epilogue carries a
+// residual (nothing overlaps it at one block per CU).  FAV_CONV_BIG: 0 never, 1 always
+// when Cout % 256 == 0, unset = the measured rule.
+bool conv_big(int kh, int kw, long long M, int cout_pad, int K, bool has_res) {
+    static int mode = [] { const char* e = getenv("FAV_CONV_BIG"); return e ? atoi(e) : 2; }();
+    if (mode == 0 || cout_pad % 256 != 0 || M < 16384) return false;
+    if (mode == 1) return true;
+    return !has_res && (kh * kw > 1 || K >= 512);
+}
+
 const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int ldy, hipStream_t s) {
     if (d.Cin % 64 != 0) return "conv: Cin must be a multiple of 64";
     if (cout_pad % 64 != 0) return "conv: padded Cout must be a multiple of 64";
@@ -199,8 +238,10 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     p.relu = d.relu; p.out_f32 = d.out_f32;
     p.drop = make_drop(&d.drop);
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
-    const int BM = 128;
-    const int BN = (cout_pad % 128 == 0) ? 128 : 64;
+    const bool big = conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
+    const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
+    const int BK = big ? 64 : conv_bk(d.kh, d.kw);
+    const int BM = big ? 256 : conv_bm(d.kh, d.kw, M);
     {   // LDS-DMA offsets are 32-bit from the tile's first frame; out-of-range lanes use 0x80000000
         const double frame_bytes = 2.0 * d.H * d.W * d.Cin;
         const double span = (BM / (double)p.HWo + 2.0) * frame_bytes + 2.0 * ((double)d.pad * d.W + d.pad) * d.Cin +
@@ -215,17 +256,28 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const double bytes = 2.0 * ((double)d.n_frames * d.H * d.W * d.Cin + (double)M * d.Cout * (d.res ? 2 : 1) * (d.out_f32 ? 2 : 1)
                                 + (double)d.Cout * p.K);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
-    dim3 grid((unsigned)tiles), block(256);
-    const int BK = conv_bk(d.kh, d.kw);
+    dim3 grid((unsigned)tiles);
     p.nk = p.K / BK;
-#define FAV_LAUNCH(BN_, BK_, MODE_) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, MODE_>), grid, block, 0, s, p)
-    if (d.math_mode == FAV_MATH_BF16) {
-        if (BN == 128) { if (BK == 32) FAV_LAUNCH(128, 32, 0); else FAV_LAUNCH(128, 64, 0); }
-        else           { if (BK == 32) FAV_LAUNCH(64, 32, 0);  else FAV_LAUNCH(64, 64, 0); }
-    } else {
-        if (BN == 128) { if (BK == 32) FAV_LAUNCH(128, 32, 1); else FAV_LAUNCH(128, 64, 1); }
-        else           { if (BK == 32) FAV_LAUNCH(64, 32, 1);  else FAV_LAUNCH(64, 64, 1); }
-    }
+    const int NS = conv_ns(BK);
+#define FAV_LAUNCH(BN_, BK_, NS_, MODE_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_>), grid, dim3(256), 0, s, p)
+#define FAV_LAUNCH_NS(BN_, BK_, MODE_)                                                            \
+    do {                                                                                          \
+        if (NS == 2) FAV_LAUNCH(BN_, BK_, 2, MODE_);                                              \
+        else if (NS == 3) FAV_LAUNCH(BN_, BK_, 3, MODE_);                                         \
+        else FAV_LAUNCH(BN_, BK_, 4, MODE_);                                                      \
+    } while (0)
+#define FAV_LAUNCH_MODE(MODE_)                                                                    \
+    do {                                                                                          \
+        if (BN == 128) { if (BK == 32) FAV_LAUNCH_NS(128, 32, MODE_); else FAV_LAUNCH_NS(128, 64, MODE_); } \
+        else { if (BK == 32) FAV_LAUNCH_NS(64, 32, MODE_); else FAV_LAUNCH_NS(64, 64, MODE_); }   \
+    } while (0)
+    if (big) {
+        if (d.math_mode == FAV_MATH_BF16) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 1>), grid, dim3(512), 0, s, p);
+    } else if (d.math_mode == FAV_MATH_BF16) FAV_LAUNCH_MODE(0); else FAV_LAUNCH_MODE(1);
+#undef FAV_LAUNCH_MODE
+#undef FAV_LAUNCH_NS
 #undef FAV_LAUNCH
     return nullptr;
 }
@@ -513,21 +565,53 @@ fav_status plan_memory(fav_handle* h) {
         const long long dom = p.suffix ? nv_max : c.max_batch;
         p.chunk = (int)std::max<long long>(1, std::min(chunk, dom));
     }
+    // pipeline the last two phases when they cover the same frames (both suffix, or both
+    // prefix when there is no MC-Dropout): FAV_PIPE = number of chunks.  Default 1 = off:
+    // measured on MI355X the two kernels only time-share the CUs (each already fills every
+    // CU's LDS), 118.5 ms/step off vs 119.0-121.2 with 2..16 chunks.
+    {
+        static int npipe = [] { const char* e = getenv("FAV_PIPE"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+        const size_t np = h->phases.size();
+        h->pipe_first = -1;
+        if (npipe > 1 && np >= 2 && h->phases[np - 1].suffix == h->phases[np - 2].suffix) {
+            const long long dom = h->phases[np - 1].suffix ? nv_max : c.max_batch;
+            if (dom >= 2 * npipe) {
+                long long step = (dom + npipe - 1) / npipe;
+                if (c.chunk_a > 0) step = std::min<long long>(step, c.chunk_a);
+                step = std::min<long long>(step, std::min(h->phases[np - 2].chunk, h->phases[np - 1].chunk));
+                h->phases[np - 2].chunk = h->phases[np - 1].chunk = (int)step;
+                h->pipe_first = (int)np - 2;
+            }
+        }
+    }
     int max_chunk = 1;
     for (const Phase& p : h->phases) max_chunk = std::max(max_chunk, p.chunk);
     // rotating buffers sized for the largest (chunk x tensor) in any phase
-    size_t act_bytes = 0, a1_bytes = 0;
-    for (const Phase& p : h->phases)
+    size_t act_bytes = 0, act2_bytes = 0, a1_bytes = 0;
+    for (size_t pi = 0; pi < h->phases.size(); ++pi) {
+        const Phase& p = h->phases[pi];
+        const bool second = h->pipe_first >= 0 && (int)pi == h->pipe_first + 1;
         for (int k = p.op_begin; k < p.op_end; ++k) {
             const Op& o = h->ops[k];
             const size_t b = (size_t)o.out_elems * (o.out_f32 ? 4 : 2) * p.chunk;
             if (o.out == B_A1) a1_bytes = std::max(a1_bytes, b);
-            else if (o.out >= 0) act_bytes = std::max(act_bytes, b);
+            else if (o.out >= 0) (second ? act2_bytes : act_bytes) = std::max(second ? act2_bytes : act_bytes, b);
         }
+    }
     act_bytes = (act_bytes + 255) / 256 * 256 + 256;
     a1_bytes = (a1_bytes + 255) / 256 * 256 + 256;
     for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&h->act[i], act_bytes));
     h->act_bytes = act_bytes;
+    if (h->pipe_first >= 0) {
+        act2_bytes = (act2_bytes + 255) / 256 * 256 + 256;
+        for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&h->act2[i], act2_bytes));
+        h->act2_bytes = act2_bytes;
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream_a, hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join_a, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join_b, hipEventDisableTiming));
+    }
     HIP_TRY(h, hipMalloc(&h->a1, a1_bytes));
     h->a1_bytes = a1_bytes;
     h->phase_out.assign(h->phases.size(), nullptr);
@@ -542,8 +626,8 @@ fav_status plan_memory(fav_handle* h) {
 }
 
 // ------------------------------------------------------------------ execution
-fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, int n, long long first_index,
-                     hipStream_t s) {
+fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, int n, long long first_index,
+                      hipStream_t s, long long v_begin, long long v_end, void** act_set) {
     const fav_config& c = h->cfg;
     const Phase& p = h->phases[pi];
     const long long dom = p.suffix ? (long long)n * h->T_eff : n;
@@ -556,8 +640,9 @@ fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, i
     const float scale = thr > 0 ? (float)(1.0 / (1.0 - thr / 256.0)) : 1.0f;
     float istd[3] = {1.0f / c.stdev[0], 1.0f / c.stdev[1], 1.0f / c.stdev[2]};
 
-    for (long long v0 = 0; v0 < dom; v0 += p.chunk) {
-        const int cn = (int)std::min<long long>(p.chunk, dom - v0);
+    (void)dom;
+    for (long long v0 = v_begin; v0 < v_end; v0 += p.chunk) {
+        const int cn = (int)std::min<long long>(p.chunk, v_end - v0);
         auto buf = [&](int id, bool is_out, const Op& o) -> void* {
             switch (id) {
                 case B_INPUT: return (void*)(pin_base + (size_t)v0 * o.in_elems * in_bpe);
@@ -567,7 +652,7 @@ fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, i
                 case B_PHASE_OUT: return (void*)(pout_base + (size_t)v0 * p.out_elems * p.out_bytes_per_elem);
                 case B_A1: return h->a1;
                 case B_NONE: return nullptr;
-                default: return h->act[id];
+                default: return act_set[id];
             }
         };
         for (int k = p.op_begin; k < p.op_end; ++k) {
@@ -620,6 +705,13 @@ fav_status run_phase(fav_handle* h, size_t pi, const void* images, int layout, i
 void free_all(fav_handle* h) {
     for (auto& L : h->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); L.w = nullptr; L.b = nullptr; }
     for (int i = 0; i < 5; ++i) if (h->act[i]) (void)hipFree(h->act[i]);
+    for (int i = 0; i < 5; ++i) if (h->act2[i]) (void)hipFree(h->act2[i]);
+    if (h->stream_a) (void)hipStreamDestroy(h->stream_a);
+    if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join_a) (void)hipEventDestroy(h->ev_join_a);
+    if (h->ev_join_b) (void)hipEventDestroy(h->ev_join_b);
+    for (auto e : h->ev_chunk) (void)hipEventDestroy(e);
     if (h->a1) (void)hipFree(h->a1);
     for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
     if (h->logits) (void)hipFree(h->logits);
@@ -757,9 +849,39 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->ev_used = h->profiling ? h->ev_used : 0;
-    for (size_t pi = 0; pi < h->phases.size(); ++pi) {
-        fav_status st = run_phase(h, pi, images, layout, n, first_index, s);
+    const size_t nph = h->phases.size();
+    const size_t serial_end = h->pipe_first >= 0 ? (size_t)h->pipe_first : nph;
+    for (size_t pi = 0; pi < serial_end; ++pi) {
+        const long long dom = h->phases[pi].suffix ? (long long)n * h->T_eff : n;
+        fav_status st = run_chunks(h, pi, images, layout, n, first_index, s, 0, dom, h->act);
         if (st != FAV_OK) return st;
+    }
+    if (h->pipe_first >= 0) {
+        const size_t pa = (size_t)h->pipe_first, pb = pa + 1;
+        const long long dom = h->phases[pa].suffix ? (long long)n * h->T_eff : n;
+        const long long step = h->phases[pa].chunk;  // == phases[pb].chunk
+        HIP_TRY(h, hipEventRecord(h->ev_fork, s));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream_a, h->ev_fork, 0));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream_b, h->ev_fork, 0));
+        size_t ci = 0;
+        for (long long v0 = 0; v0 < dom; v0 += step, ++ci) {
+            const long long v1 = std::min(dom, v0 + step);
+            fav_status st = run_chunks(h, pa, images, layout, n, first_index, h->stream_a, v0, v1, h->act);
+            if (st != FAV_OK) return st;
+            if (ci >= h->ev_chunk.size()) {
+                hipEvent_t e;
+                HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->ev_chunk.push_back(e);
+            }
+            HIP_TRY(h, hipEventRecord(h->ev_chunk[ci], h->stream_a));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream_b, h->ev_chunk[ci], 0));
+            st = run_chunks(h, pb, images, layout, n, first_index, h->stream_b, v0, v1, h->act2);
+            if (st != FAV_OK) return st;
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_join_a, h->stream_a));
+        HIP_TRY(h, hipEventRecord(h->ev_join_b, h->stream_b));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_a, 0));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_b, 0));
     }
     if (const char* e = launch_head(h, h->logits, h->T_eff, n, h->cfg.num_classes, h->cpad, h->cfg.temperature,
                                     h->cfg.conf_kind, h->cfg.tau, labels, conf, fail, score, s)) {

@@ -182,19 +182,31 @@ __device__ __forceinline__ int lds_swz(int row) {
     return BK == 64 ? (row & 7) : ((-(row >> 2)) & 3);
 }
 
-template <int BM, int BN, int BK, int MODE>
-__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
+// waves per SIMD the LDS footprint allows (what __launch_bounds__ should ask for)
+constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
+    const int stage = NS * (BM + BN) * BK * 2, out = 64 * (BN + 4) * 4;
+    const int lds = stage > out ? stage : out;
+    int blocks = 163840 / lds;
+    if (blocks > 4) blocks = 4;
+    if (blocks < 1) blocks = 1;
+    return blocks * (BM * 2 / 64) / 4;
+}
+
+template <int BM, int BN, int BK, int NS, int MODE>
+__global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int NT = BM * 2;                  // threads: (BM/64) x 2 waves, each a 64 x BN/2 sub-tile
+    constexpr int NWAVES = NT / 64;
     constexpr int ROWB = BK * 2;                // bytes per staged row
     constexpr int CPR = BK / 8;                 // 16-B chunks per row
     constexpr int PROWS = 1024 / ROWB;          // rows per 1-KiB LDS-DMA piece
-    constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
+    constexpr int WTM = 64, WTN = BN / 2;       // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16; // 16x16 MFMA tiles per wave
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int OUT_LD = BN + 4;              // fp32 staging row stride (floats)
-    constexpr int OUT_BYTES = (BM / 2) * OUT_LD * 4;  // the epilogue stages half a tile at a time
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > OUT_BYTES) ? 2 * STAGE_BYTES : OUT_BYTES;
-    constexpr int AR = A_BYTES / 4096, BR = B_BYTES / 4096;  // LDS-DMA pieces per wave per tile
+    constexpr int OUT_BYTES = 64 * OUT_LD * 4;  // the epilogue stages 64 rows (one wave row) at a time
+    constexpr int LDS_BYTES = (NS * STAGE_BYTES > OUT_BYTES) ? NS * STAGE_BYTES : OUT_BYTES;
+    constexpr int AR = A_BYTES / 1024 / NWAVES, BR = B_BYTES / 1024 / NWAVES;  // LDS-DMA pieces per wave per tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -296,13 +308,21 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
     const int frow = lane & 15;  // row of the 16-row fragment this lane reads
     const int fq = lane >> 4;    // which 8-element k chunk of a 32-wide k step
 
-    FAV_STAGE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NS-stage ring: tiles kt+1 .. kt+NS-1 are in flight while tile kt is multiplied.
+    // vmcnt counts this wave's LDS-DMA pieces in issue order, so "all but the newest
+    // (NS-2) tiles have landed" is the counted wait below; the barrier then makes
+    // every wave's share of tile kt+1 visible.
+    constexpr int PIECES = AR + BR;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < p.nk) FAV_STAGE(t, t);
+    if (p.nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int cur = 0, nxt = NS - 1;  // stage being read / stage being filled
     for (int kt = 0; kt < p.nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < p.nk) FAV_STAGE(cur ^ 1, kt + 1);
+        if (kt + NS - 1 < p.nk) FAV_STAGE(nxt, kt + NS - 1);
         const unsigned char* As = smem + cur * STAGE_BYTES;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -349,45 +369,50 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed
+        // tile kt+1 has landed (its successors may still be in flight)
+        if (kt + NS - 1 < p.nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 
     // ---- epilogue ----------------------------------------------------------------
-    // Half a tile (BM/2 rows = the rows of one wave row wm) goes through LDS at a time
-    // so the staging area stays under the K-loop stages (more blocks per CU).  A thread
+    // 64 rows (= the rows of one wave row wm) go through LDS at a time so the staging
+    // area stays under the K-loop stages (more blocks per CU).  A thread
     // finishes 16 consecutive channels of one output pixel per pass (two 16-B stores;
     // one Philox call covers exactly its 16 dropout draws).  Residual rows are requested
     // BEFORE the accumulators go through LDS so their latency hides behind the staging
     // barrier.  (The barrier that ended the K loop already separates the last fragment
     // reads from the first staging writes.)
     constexpr int NCH = BN / 16;           // 16-channel chunks per row
-    constexpr int RPP = 256 / NCH;         // rows per pass
-    constexpr int NPASS = (BM / 2) / RPP;  // passes per half tile
+    constexpr int RPP = (NT / NCH > 64) ? 64 : NT / NCH;  // rows per pass (threads beyond 64 rows idle)
+    constexpr int NPASS = 64 / RPP;        // passes per 64-row group
+    constexpr int NGROUPS = BM / 64;
     const int ec = tid % NCH, er = tid / NCH;
     const int n = n0 + ec * 16;
     float* outs = (float*)smem;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NGROUPS; ++half) {
         uint4 rres[NPASS][2];
         if (p.res) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
-                const int m = m0 + half * (BM / 2) + er + pass * RPP;
-                if (m < p.M && n < p.Cout) {
+                const int m = m0 + half * 64 + er + pass * RPP;
+                if (er < 64 && m < p.M && n < p.Cout) {
                     const uint4* rp = (const uint4*)(p.res + (long long)m * p.ldy + n);
                     rres[pass][0] = rp[0];
                     rres[pass][1] = rp[1];
                 }
             }
         }
-        if (half == 1) __syncthreads();  // everyone is done reading the first half
+        if (half > 0) __syncthreads();  // everyone is done reading the previous group
         if (wm == half) {
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b) {
-                    const int ml = b * 16 + frow;  // row inside the half tile
+                    const int ml = b * 16 + frow;  // row inside the 64-row group
                     const int nl = wn * WTN + a * 16 + fq * 4;
                     *(f32x4_t*)(outs + ml * OUT_LD + nl) = acc[a][b];
                 }
@@ -396,8 +421,8 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int ml = er + pass * RPP;
-            const int m = m0 + half * (BM / 2) + ml;
-            if (m >= p.M || n >= p.Cout) continue;
+            const int m = m0 + half * 64 + ml;
+            if (er >= 64 || m >= p.M || n >= p.Cout) continue;
             uint32_t keep = 0xFFFFu;
             if (!p.out_f32 && p.drop.site >= 0) {
                 const int vl = m / p.HWo;

@@ -145,6 +145,13 @@ def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = Non
         fan_in = spec["kh"] * spec["kw"] * spec["cin"]
         gain = 1.0 if spec["role"] == "down" else 2.0
         w = rng.standard_normal((spec["cout"], spec["kh"], spec["kw"], spec["cin"])) * np.sqrt(gain / fan_in)
+        if spec["role"] == "stem":
+            # smooth (low-pass) first-layer filters, as a trained stem has: white pixel noise
+            # then excites the network far less than image content does, which keeps the
+            # labels of noise-corrupted frames diverse instead of collapsing to one class
+            k1 = np.array([1.0, 4.0, 6.0, 4.0, 1.0]) / 16.0
+            for ax in (1, 2):
+                w = np.apply_along_axis(lambda v: np.convolve(v, k1, mode="same"), ax, w)
         acc = _conv64(inp, w, spec["stride"], spec["pad"])
         mu = _bf16_f32(acc.mean(axis=(0, 1, 2))).astype(np.float64)
         var = _bf16_f32(acc.var(axis=(0, 1, 2))).astype(np.float64)

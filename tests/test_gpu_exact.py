@@ -26,6 +26,8 @@ def lib():
 @pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,n", [
     (64, 64, 1, 1, 0, 14, 14, 3), (64, 128, 3, 2, 1, 15, 15, 2), (128, 256, 3, 1, 1, 9, 9, 2),
     (512, 128, 1, 1, 0, 7, 7, 3), (192, 64, 1, 1, 0, 16, 16, 2), (256, 512, 1, 2, 0, 14, 14, 1),
+    (64, 128, 3, 1, 1, 40, 44, 10),   # M=17600
+    (64, 256, 3, 1, 1, 40, 44, 10),   # M=17600, Cout 256 -> the 256x256 tile (8 waves)
 ])
 def test_conv_exact_bitwise(lib, cin, cout, k, stride, pad, H, W, n):
     rng = np.random.default_rng(cin + cout + k)

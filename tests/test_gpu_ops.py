@@ -66,6 +66,10 @@ CONV_CASES = [
     (512, 128, 1, 1, 0, 5, 5, 1, False),      # M=25: a single partial tile
     (192, 64, 1, 1, 0, 16, 16, 2, False),     # the stem GEMM shape (K=192)
     (64, 64, 3, 1, 1, 56, 56, 1, True),       # 25 tiles, tail tile of 64 rows
+    (64, 64, 3, 1, 1, 56, 56, 6, True),       # M=18816 -> 256-row tiles (8 waves), BN=64, ragged last tile
+    (128, 128, 3, 2, 1, 57, 57, 21, True),    # M=17661, stride 2, odd size
+    (128, 256, 3, 1, 1, 30, 30, 19, False),   # M=17100, Cout 256, no residual -> the 256x256 tile (8 waves)
+    (512, 256, 1, 1, 0, 30, 30, 19, False),   # 1x1 with K=512 on the 256x256 tile
 ]
 
 
