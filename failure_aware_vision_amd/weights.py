@@ -145,7 +145,7 @@ def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = Non
         fan_in = spec["kh"] * spec["kw"] * spec["cin"]
         gain = 1.0 if spec["role"] == "down" else 2.0
         w = rng.standard_normal((spec["cout"], spec["kh"], spec["kw"], spec["cin"])) * np.sqrt(gain / fan_in)
-        if spec["role"] == "stem":
+        if spec["role"] == "stem" and spec["kh"] >= 5:
             # smooth (low-pass) first-layer filters, as a trained stem has: white pixel noise
             # then excites the network far less than image content does, which keeps the
             # labels of noise-corrupted frames diverse instead of collapsing to one class
