@@ -37,6 +37,19 @@ def algorithmic_gflop_per_frame(policy: str, T: int) -> float:
     return 2 * (prefix + T * (RESNET50_GMAC - prefix))
 
 
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of the same command
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; separate
+    passes; tools/profile.sh -> profiles/pmc_traffic.json).  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return {"bytes_per_launch": d["conv_bytes_per_launch"], "fetch_bytes_per_launch": d["conv_fetch_bytes_per_launch"],
+                "write_bytes_per_launch": d["conv_write_bytes_per_launch"], "source": d["source"]}
+    except Exception:
+        return None
+
+
 def cpu_baseline(blob, args, T, policy):
     """The oracle's torch-CPU port on a bounded sample of the same workload (same
     weights, corruption, masks and prefix caching), timed on this host's cores."""
@@ -152,15 +165,21 @@ def main():
         }
         if prof is not None:
             cv = prof["conv_igemm"]
-            ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12 if cv["ms"] > 0 else 0.0
+            secs = cv["ms"] * 1e-3
             total_ms = sum(v["ms"] for v in prof.values())
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all conv/fc launches)",
-                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                               "avg_launch_us": 1000.0 * cv["ms"] / max(1, cv["launches"]),
-                               "launches": cv["launches"],
-                               "algorithmic_hbm_gbs": cv["bytes"] / (cv["ms"] * 1e-3) / 1e9 if cv["ms"] > 0 else 0.0,
-                               "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None}
+            tf = cv["flops"] / secs / 1e12 if secs > 0 else 0.0
+            gbs = cv["bytes"] / secs / 1e9 if secs > 0 else 0.0
+            common = {"kernel": "fav::conv_igemm_kernel (every conv / fc launch of the timed steps)",
+                      "launches": cv["launches"], "avg_launch_us": 1e3 * cv["ms"] / max(1, cv["launches"]),
+                      "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None,
+                      "timing": "HIP events recorded on the launch stream around every launch, inside the timed region"}
+            # The unfused layer-by-layer workload is HBM-bound overall (186 FLOP/B algorithmic vs
+            # 312 FLOP/B machine balance), so the binding roofline is HBM.
+            out["roofline"] = dict(common, bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                                   frac=gbs / PEAK_HBM_GBS, traffic=pmc_traffic(),
+                                   algorithmic_bytes_per_launch=cv["bytes"] / max(1, cv["launches"]))
+            out["roofline_mfma"] = dict(common, bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                                        frac=tf / PEAK_BF16_TFLOPS, traffic=None)
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
         if args.cpu_frames > 0:
             try:

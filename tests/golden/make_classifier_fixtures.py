@@ -1,0 +1,64 @@
+"""Generates the classifier golden fixtures with the CPU oracle in exact mode
+(oracle/fav_exact.c order; bit-reproducible).  Inputs are regenerated from seeds, so
+the fixtures hold only expected outputs.
+
+  python tests/golden/make_classifier_fixtures.py mc      # 64 frames, T=30 all_blocks  (~10 min on 8 cores)
+  python tests/golden/make_classifier_fixtures.py 10k     # 10,000 frames, single pass  (~1 h on 8 cores)
+"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from failure_aware_vision_amd import synth, weights
+from oracle import fav_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FRAME_SEED, NOISE_SEED, SEVERITY = 21, 3, 3
+blob, info = weights.make_synthetic("resnet50", seed=1)
+model = O.parse_blob(blob)
+
+
+def frames(start, n):
+    u8 = synth.synthetic_frames_u8(n, 224, 224, seed=FRAME_SEED, start_id=start)
+    return synth.gaussian_noise_f32(u8, SEVERITY, seed=NOISE_SEED, start_id=start)
+
+
+def gap_of(pbar):
+    s = np.sort(pbar, axis=1)
+    return (s[:, -1] - s[:, -2]).astype(np.float32)
+
+
+what = sys.argv[1] if len(sys.argv) > 1 else "mc"
+if what == "mc":
+    n, T = 64, 30
+    cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact=True)
+    labels, conf, gaps = [], [], []
+    for s in range(0, n, 8):
+        t0 = time.time()
+        l, c, lg, pb = O.classify(model, frames(s, 8), cfg, img_ids=np.arange(s, s + 8), return_logits=True)
+        labels.append(l); conf.append(c); gaps.append(gap_of(pb))
+        print("mc", s, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "r50_exact_mc30_64.npz"), labels=np.concatenate(labels).astype(np.int16),
+                        conf=np.concatenate(conf), gap=np.concatenate(gaps), blob_sha256=info["sha256"],
+                        meta="resnet50 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; exact")
+else:
+    n, bs = 10000, 50
+    part = os.path.join(HERE, "_10k_partial.npz")
+    done = 0
+    labels = np.zeros(n, np.int16); conf = np.zeros(n, np.float32); gaps = np.zeros(n, np.float32)
+    if os.path.exists(part):
+        d = np.load(part); done = int(d["done"]); labels, conf, gaps = d["labels"], d["conf"], d["gap"]
+    cfg = O.ClassifyConfig(exact=True)
+    t0 = time.time()
+    for s in range(done, n, bs):
+        l, c, lg, pb = O.classify(model, frames(s, bs), cfg, return_logits=True)
+        labels[s:s + bs] = l; conf[s:s + bs] = c; gaps[s:s + bs] = gap_of(pb)
+        if (s // bs) % 10 == 9:
+            np.savez(part, done=s + bs, labels=labels, conf=conf, gap=gaps)
+            print("10k", s + bs, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "r50_exact_10k_noise3.npz"), labels=labels, conf=conf, gap=gaps,
+                        blob_sha256=info["sha256"],
+                        meta="resnet50 seed1; frames seed 21 ids 0..9999 + gaussian noise sev3 seed 3; single pass; exact")
+    if os.path.exists(part):
+        os.remove(part)
+print("done")

@@ -28,3 +28,26 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
         print("  ", k)
         for c, v in d.items():
             print("      %-28s sum %.4g  per-dispatch %.4g  (n=%d)" % (c, v, v / n[(k, c)], n[(k, c)]))
+
+# HBM traffic of the conv kernel per launch -> profiles/pmc_traffic.json (read by bench.py)
+import json
+def conv_sum(sub, counter):
+    f = find(sub, "*counter_collection.csv")
+    tot, n = 0.0, 0
+    if f:
+        for row in csv.DictReader(open(f)):
+            if "conv_igemm_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                tot += float(row["Counter_Value"]); n += 1
+    return tot, n
+fs, fn = conv_sum("pmc_fetch", "FETCH_SIZE")
+ws, wn = conv_sum("pmc_write", "WRITE_SIZE")
+if fn and wn:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2
+    fetch = fs * 1024.0 * 2.0 / fn
+    write = ws * 1024.0 / wn
+    d = {"conv_fetch_bytes_per_launch": fetch, "conv_write_bytes_per_launch": write,
+         "conv_bytes_per_launch": fetch + write, "launches_profiled": fn,
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1`, "
+                   "FETCH_SIZE x2 (gfx950 correction), " + os.path.basename(out.rstrip('/'))}
+    json.dump(d, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print("pmc_traffic", d)
