@@ -32,7 +32,7 @@ class FavConfig(C.Structure):
         ("mean", C.c_float * 3), ("stdev", C.c_float * 3),
         ("n_samples", C.c_int32), ("site_mask", C.c_uint32), ("dropout_p", C.c_float), ("seed", C.c_uint64),
         ("temperature", C.c_float), ("conf_kind", C.c_int32), ("tau", C.c_float), ("math_mode", C.c_int32),
-        ("chunk_a", C.c_int32), ("chunk_b", C.c_int32), ("regroup_block", C.c_int32),
+        ("chunk_a", C.c_int32), ("chunk_b", C.c_int32), ("regroup_block", C.c_int32), ("n_members", C.c_int32),
     ]
 
 
@@ -65,6 +65,7 @@ _SIGNATURES = {
     "fav_default_config": (None, [C.POINTER(FavConfig), C.c_int32]),
     "fav_create": (C.c_int, [C.POINTER(FavConfig), C.POINTER(C.c_void_p)]),
     "fav_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fav_load_member_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "fav_destroy": (None, [C.c_void_p]),
     "fav_last_error": (C.c_char_p, [C.c_void_p]),
     "fav_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

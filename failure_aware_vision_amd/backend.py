@@ -65,21 +65,27 @@ class Backend:
         cfg.tau = float(tau)
         cfg.math_mode = _MATH[math_mode]
         cfg.chunk_a, cfg.chunk_b, cfg.regroup_block = int(chunk_a), int(chunk_b), int(regroup_block)
+        members = list(blob) if isinstance(blob, (list, tuple)) else None   # deep ensemble: one blob per member
+        cfg.n_members = len(members) if members else 1
         self.cfg = cfg
         h = C.c_void_p()
         _lib.check(self.lib.fav_create(C.byref(cfg), C.byref(h)))
         self._h = h
-        if blob is None:
-            blob, self.weights_info = _weights.make_synthetic(arch, seed=seed_weights, num_classes=cfg.num_classes)
-        self.load_weights(blob)
+        if members:
+            for i, b in enumerate(members):
+                self.load_weights(b, member=i)
+        else:
+            if blob is None:
+                blob, self.weights_info = _weights.make_synthetic(arch, seed=seed_weights, num_classes=cfg.num_classes)
+            self.load_weights(blob)
         self.mc = cfg.site_mask != 0 and round(cfg.dropout_p * 256) > 0
-        self.T = cfg.n_samples if self.mc else 1
+        self.T = cfg.n_samples if self.mc else max(1, cfg.n_members)
         self._prev_status_provider = None
 
     # -- lifecycle ------------------------------------------------------------
-    def load_weights(self, blob: bytes):
+    def load_weights(self, blob: bytes, member: int = 0):
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _lib.check(self.lib.fav_load_weights(self._h, buf, len(blob)), self._h)
+        _lib.check(self.lib.fav_load_member_weights(self._h, int(member), buf, len(blob)), self._h)
 
     def reset(self):
         """Scorer reset on mode switch (main.py:222,227,242,288).  The classifier is stateless."""

@@ -58,8 +58,10 @@ const ArchDef kArch[2] = {
 struct Layer {  // one convolution / fc
     int cout, cin, kh, kw, stride, pad;
     int cout_pad, k;         // device layout: w[cout_pad][k], bias[cout_pad]
-    uint16_t* w = nullptr;
+    uint16_t* w = nullptr;          // weights / bias of the member being run
     float* b = nullptr;
+    std::vector<uint16_t*> w_m;     // per ensemble member
+    std::vector<float*> b_m;
 };
 
 enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT };
@@ -95,6 +97,8 @@ struct fav_handle {
     std::vector<Op> ops;
     std::vector<Phase> phases;
     bool weights_loaded = false;
+    std::vector<char> member_loaded;   // deep ensemble (BASELINE configs[3]): one checkpoint per member
+    int n_members = 1;
     // workspace
     void* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t act_bytes = 0;
@@ -620,7 +624,7 @@ fav_status plan_memory(fav_handle* h) {
         const long long dom = p.suffix ? nv_max : c.max_batch;
         HIP_TRY(h, hipMalloc(&h->phase_out[i], (size_t)dom * p.out_elems * p.out_bytes_per_elem + 256));
     }
-    HIP_TRY(h, hipMalloc((void**)&h->logits, (size_t)nv_max * h->cpad * 4 + 256));
+    HIP_TRY(h, hipMalloc((void**)&h->logits, (size_t)nv_max * h->n_members * h->cpad * 4 + 256));
     h->phase_out.back() = h->logits;
     return FAV_OK;
 }
@@ -703,7 +707,11 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
 }
 
 void free_all(fav_handle* h) {
-    for (auto& L : h->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); L.w = nullptr; L.b = nullptr; }
+    for (auto& L : h->layers) {
+        for (auto pw : L.w_m) if (pw) (void)hipFree(pw);
+        for (auto pb : L.b_m) if (pb) (void)hipFree(pb);
+        L.w_m.clear(); L.b_m.clear(); L.w = nullptr; L.b = nullptr;
+    }
     for (int i = 0; i < 5; ++i) if (h->act[i]) (void)hipFree(h->act[i]);
     for (int i = 0; i < 5; ++i) if (h->act2[i]) (void)hipFree(h->act2[i]);
     if (h->stream_a) (void)hipStreamDestroy(h->stream_a);
@@ -748,6 +756,7 @@ void fav_default_config(fav_config* c, int32_t arch) {
     c->tau = 0.5f;
     c->math_mode = FAV_MATH_BF16;
     c->chunk_a = 0; c->chunk_b = 0; c->regroup_block = -1;
+    c->n_members = 1;
 }
 
 const char* fav_last_error(const fav_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -760,7 +769,8 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out) {
     if (cfg->num_classes < 1 || cfg->num_classes > 1024 || cfg->max_batch < 1 || cfg->in_h < 8 || cfg->in_w < 8 ||
         cfg->n_samples < 1 || cfg->n_samples > 4096 || !(cfg->temperature > 0.f) || cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f ||
         !(cfg->stdev[0] > 0.f && cfg->stdev[1] > 0.f && cfg->stdev[2] > 0.f) || cfg->math_mode < 0 || cfg->math_mode > 1 ||
-        cfg->conf_kind < 0 || cfg->conf_kind > 1) {
+        cfg->conf_kind < 0 || cfg->conf_kind > 1 || cfg->n_members < 0 || cfg->n_members > 64 ||
+        (cfg->n_members > 1 && cfg->site_mask != 0 && cfg->dropout_p > 0.f)) {   // ensemble members are deterministic
         g_create_error = "fav_create: config value out of range";
         return FAV_ERR_INVALID_ARG;
     }
@@ -777,6 +787,8 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out) {
     }
     fav_handle* h = new fav_handle();
     h->cfg = *cfg;
+    h->n_members = cfg->n_members > 1 ? cfg->n_members : 1;
+    h->member_loaded.assign(h->n_members, 0);
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; delete h; return FAV_ERR_HIP; }
     fav_status st = build_graph(h);
     if (st == FAV_OK) st = plan_memory(h);
@@ -793,8 +805,11 @@ void fav_destroy(fav_handle* h) {
     delete h;
 }
 
-fav_status fav_load_weights(fav_handle* h, const void* blob, size_t size) {
+fav_status fav_load_weights(fav_handle* h, const void* blob, size_t size) { return fav_load_member_weights(h, 0, blob, size); }
+
+fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* blob, size_t size) {
     if (!h) return FAV_ERR_INVALID_ARG;
+    if (member < 0 || member >= h->n_members) { h->err = fmt("fav_load_member_weights: member %d outside [0, %d)", member, h->n_members); return FAV_ERR_INVALID_ARG; }
     if (!blob || size < 32) { h->err = "fav_load_weights: blob too small"; return FAV_ERR_BAD_BLOB; }
     const uint8_t* p = (const uint8_t*)blob;
     uint32_t hdr[8];
@@ -829,12 +844,16 @@ fav_status fav_load_weights(fav_handle* h, const void* blob, size_t size) {
         for (int n = 0; n < L.cout; ++n) memcpy(&wtmp[(size_t)n * L.k], src + (size_t)n * kreal, kreal * 2);
         btmp.assign(L.cout_pad, 0.f);
         memcpy(btmp.data(), p + off[1], bbytes);
-        if (!L.w) HIP_TRY(h, hipMalloc((void**)&L.w, wtmp.size() * 2));
-        if (!L.b) HIP_TRY(h, hipMalloc((void**)&L.b, btmp.size() * 4));
-        HIP_TRY(h, hipMemcpy(L.w, wtmp.data(), wtmp.size() * 2, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(L.b, btmp.data(), btmp.size() * 4, hipMemcpyHostToDevice));
+        L.w_m.resize(h->n_members, nullptr);
+        L.b_m.resize(h->n_members, nullptr);
+        if (!L.w_m[member]) HIP_TRY(h, hipMalloc((void**)&L.w_m[member], wtmp.size() * 2));
+        if (!L.b_m[member]) HIP_TRY(h, hipMalloc((void**)&L.b_m[member], btmp.size() * 4));
+        HIP_TRY(h, hipMemcpy(L.w_m[member], wtmp.data(), wtmp.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(L.b_m[member], btmp.data(), btmp.size() * 4, hipMemcpyHostToDevice));
     }
+    h->member_loaded[member] = 1;
     h->weights_loaded = true;
+    for (char c : h->member_loaded) h->weights_loaded = h->weights_loaded && c;
     return FAV_OK;
 }
 
@@ -849,6 +868,10 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->ev_used = h->profiling ? h->ev_used : 0;
+    for (int member = 0; member < h->n_members; ++member) {
+    for (auto& L : h->layers) { L.w = L.w_m[member]; L.b = L.b_m[member]; }
+    // member m writes logits[m][n][cpad]: the head then averages members exactly as it averages samples
+    h->phase_out.back() = (char*)h->logits + (size_t)member * n * h->cpad * 4;
     const size_t nph = h->phases.size();
     const size_t serial_end = h->pipe_first >= 0 ? (size_t)h->pipe_first : nph;
     for (size_t pi = 0; pi < serial_end; ++pi) {
@@ -883,13 +906,16 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_a, 0));
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_b, 0));
     }
-    if (const char* e = launch_head(h, h->logits, h->T_eff, n, h->cfg.num_classes, h->cpad, h->cfg.temperature,
+    }
+    h->phase_out.back() = h->logits;
+    const int T_head = h->n_members > 1 ? h->n_members : h->T_eff;
+    if (const char* e = launch_head(h, h->logits, T_head, n, h->cfg.num_classes, h->cpad, h->cfg.temperature,
                                     h->cfg.conf_kind, h->cfg.tau, labels, conf, fail, score, s)) {
         h->err = e;
         return FAV_ERR_INVALID_ARG;
     }
     HIP_TRY(h, hipGetLastError());
-    h->last_T = h->T_eff;
+    h->last_T = T_head;
     h->last_n = n;
     return FAV_OK;
 }
@@ -1021,6 +1047,19 @@ fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t C, int
                        float tau, int32_t* labels, float* conf, uint8_t* fail, float* score, void* stream) {
     if (!logits || !labels || !conf || T < 1 || n < 1 || !(temperature > 0.f)) return op_done("fav_op_head: bad argument");
     return op_done(launch_head(nullptr, logits, T, n, C, ld, temperature, kind, tau, labels, conf, fail, score, (hipStream_t)stream));
+}
+
+fav_status fav_op_signal_stats(const uint8_t* frames, int32_t n, int32_t H, int32_t W, const uint8_t* prev_gray,
+                               uint8_t* last_gray, fav_signal_stats* stats, void* stream) {
+    static_assert(sizeof(fav_signal_stats) == sizeof(SignalStats), "fav_signal_stats layout");
+    if (!frames || !stats || n < 1 || H < 3 || W < 4 || W % 4 != 0 || (long long)H * W > 150000)
+        return op_done("fav_op_signal_stats: bad argument (need W % 4 == 0, 3 <= H, H*W <= 150000)");
+    const size_t lds = (((size_t)H * W + 15) & ~(size_t)15) + 1024 * 4 + 16 * 8;
+    if (hipFuncSetAttribute((const void*)signal_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return op_done("fav_op_signal_stats: cannot reserve LDS for the gray plane");
+    hipLaunchKernelGGL(signal_stats_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, frames, n, H, W, prev_gray,
+                       last_gray, (SignalStats*)stats);
+    return op_done(nullptr);
 }
 
 }  // extern "C"

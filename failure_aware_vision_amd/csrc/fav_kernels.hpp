@@ -700,3 +700,117 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ log
 }
 
 }  // namespace fav
+
+// ===========================================================================
+// SignalAnalyzer.analyze_frame as ONE fused pass per frame (SURVEY.md §8f row 2;
+// reference: platform/backend/signal_analyzer.py:62-112).  Per uint8 BGR frame:
+//   gray     = (1868*B + 9617*G + 4899*R + 8192) >> 14            (cv2.COLOR_BGR2GRAY, 8-bit)
+//   lap      = 4-neighbour Laplacian of gray, BORDER_REFLECT_101   (cv2.Laplacian ksize=1)
+//   sums     = sum gray, sum |gray - prev_gray|, sum lap, sum lap^2, 256-bin histogram
+// One block per frame keeps the whole gray plane in LDS (H*W <= 150 KB), so the frame
+// is read from HBM exactly once (plus once more as the predecessor of the next frame:
+// inside a batch the previous gray is recomputed from frame i-1 rather than exchanged
+// between blocks).  All accumulations are integers, hence exact; the derived floats are
+// computed from them at the end.
+// ===========================================================================
+namespace fav {
+
+struct SignalStats {       // mirrors fav_signal_stats in include/fav.h
+    double lap_var, mean, mean_diff;
+    float entropy;
+    int has_prev;
+    long long sum_lap, sum_lap2;
+    unsigned int sum_gray, sum_absdiff;
+    unsigned int hist[256];
+};
+
+__device__ __forceinline__ uint32_t bgr_quad_to_gray(const uint32_t* p3) {
+    // 4 pixels = 12 bytes = 3 dwords: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    const uint32_t w0 = p3[0], w1 = p3[1], w2 = p3[2];
+    const uint32_t b0 = w0 & 255, g0 = (w0 >> 8) & 255, r0 = (w0 >> 16) & 255, b1 = w0 >> 24;
+    const uint32_t g1 = w1 & 255, r1 = (w1 >> 8) & 255, b2 = (w1 >> 16) & 255, g2 = w1 >> 24;
+    const uint32_t r2 = w2 & 255, b3 = (w2 >> 8) & 255, g3 = (w2 >> 16) & 255, r3 = w2 >> 24;
+    const uint32_t y0 = (1868u * b0 + 9617u * g0 + 4899u * r0 + 8192u) >> 14;
+    const uint32_t y1 = (1868u * b1 + 9617u * g1 + 4899u * r1 + 8192u) >> 14;
+    const uint32_t y2 = (1868u * b2 + 9617u * g2 + 4899u * r2 + 8192u) >> 14;
+    const uint32_t y3 = (1868u * b3 + 9617u * g3 + 4899u * r3 + 8192u) >> 14;
+    return y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+}
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void signal_stats_kernel(const uint8_t* __restrict__ frames, int n, int H, int W,
+                                                           const uint8_t* __restrict__ prev_gray,
+                                                           uint8_t* __restrict__ last_gray, SignalStats* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int npx = H * W, nq = npx >> 2;             // W % 4 == 0
+    uint32_t* gq = (uint32_t*)dyn;                    // gray plane, 4 pixels per dword
+    unsigned int* hist = (unsigned int*)(dyn + ((npx + 15) & ~15));   // [4][256] per-wave histograms
+    long long* red = (long long*)(hist + 1024);       // [4][4] wave partials
+    const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t* cur = (const uint32_t*)(frames + (size_t)f * npx * 3);
+    const bool has_prev = f > 0 || prev_gray != nullptr;
+    const uint32_t* prv_bgr = f > 0 ? (const uint32_t*)(frames + (size_t)(f - 1) * npx * 3) : nullptr;
+    const uint32_t* prv_gray = (const uint32_t*)prev_gray;
+    for (int i = tid; i < 1024; i += 256) hist[i] = 0;
+    __syncthreads();
+    unsigned int s_gray = 0, s_diff = 0;
+    for (int q = tid; q < nq; q += 256) {
+        const uint32_t g = bgr_quad_to_gray(cur + 3 * q);
+        gq[q] = g;
+        uint32_t pg = 0;
+        if (f > 0) pg = bgr_quad_to_gray(prv_bgr + 3 * q);
+        else if (prv_gray) pg = prv_gray[q];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int y = (g >> (8 * b)) & 255, py = (pg >> (8 * b)) & 255;
+            s_gray += y;
+            s_diff += has_prev ? (unsigned)abs(y - py) : 0u;
+            atomicAdd(&hist[wave * 256 + y], 1u);
+        }
+        if (last_gray && f == n - 1) ((uint32_t*)last_gray)[q] = g;
+    }
+    __syncthreads();
+    // Laplacian from the LDS plane, reflect-101 borders: index -1 -> 1, H -> H-2
+    const uint8_t* g8 = (const uint8_t*)gq;
+    long long s_lap = 0, s_lap2 = 0;
+    for (int px = tid; px < npx; px += 256) {
+        const int y = px / W, x = px - y * W;
+        const int yu = y == 0 ? 1 : y - 1, yd = y == H - 1 ? H - 2 : y + 1;
+        const int xl = x == 0 ? 1 : x - 1, xr = x == W - 1 ? W - 2 : x + 1;
+        const int lap = (int)g8[yu * W + x] + (int)g8[yd * W + x] + (int)g8[y * W + xl] + (int)g8[y * W + xr] - 4 * (int)g8[px];
+        s_lap += lap;
+        s_lap2 += (long long)lap * lap;
+    }
+    const long long r0 = wave_sum_i64(s_gray), r1 = wave_sum_i64(s_diff), r2 = wave_sum_i64(s_lap), r3 = wave_sum_i64(s_lap2);
+    if (lane == 0) { red[wave * 4] = r0; red[wave * 4 + 1] = r1; red[wave * 4 + 2] = r2; red[wave * 4 + 3] = r3; }
+    __syncthreads();
+    // merge histograms; one bin per thread; entropy in fp32 (as the fp32 cv2.calcHist output is used)
+    const unsigned int cnt = hist[tid] + hist[256 + tid] + hist[512 + tid] + hist[768 + tid];
+    const float p = (float)cnt / (float)npx;
+    float term = cnt ? -p * log2f(p) : 0.f;
+    term = wave_sum(term);
+    __shared__ float ent_part[4];
+    if (lane == 0) ent_part[wave] = term;
+    SignalStats* o = out + f;
+    o->hist[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const long long sg = red[0] + red[4] + red[8] + red[12], sd = red[1] + red[5] + red[9] + red[13];
+        const long long sl = red[2] + red[6] + red[10] + red[14], sl2 = red[3] + red[7] + red[11] + red[15];
+        const double N = (double)npx, m = (double)sl / N;
+        o->lap_var = (double)sl2 / N - m * m;
+        o->mean = (double)sg / N;
+        o->mean_diff = has_prev ? (double)sd / N : 0.0;
+        o->entropy = ((ent_part[0] + ent_part[1]) + ent_part[2]) + ent_part[3];
+        o->has_prev = has_prev ? 1 : 0;
+        o->sum_lap = sl; o->sum_lap2 = sl2;
+        o->sum_gray = (unsigned int)sg; o->sum_absdiff = (unsigned int)sd;
+    }
+}
+
+}  // namespace fav

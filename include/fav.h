@@ -76,6 +76,8 @@ typedef struct fav_config {
     int32_t chunk_a;        /* frames per pass through the high-resolution stages (0 = auto) */
     int32_t chunk_b;        /* frames per pass through the low-resolution stages (0 = auto) */
     int32_t regroup_block;  /* first residual block of the low-resolution group (-1 = auto) */
+    int32_t n_members;      /* deep ensemble: independently trained checkpoints whose softmax is averaged
+                               (1 = single model; > 1 excludes MC-Dropout) */
 } fav_config;
 
 /* Fills *cfg with the defaults (ImageNet mean/std, T=1, no dropout, tau=0.5). */
@@ -85,7 +87,8 @@ void fav_default_config(fav_config* cfg, int32_t arch);
  * (reference lifecycle: construct on accept main.py:110-118, reset main.py:284-291,
  * drop on disconnect main.py:310-317). */
 fav_status fav_create(const fav_config* cfg, fav_handle** out);
-fav_status fav_load_weights(fav_handle* h, const void* blob_host, size_t size);
+fav_status fav_load_weights(fav_handle* h, const void* blob_host, size_t size);   /* member 0 */
+fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* blob_host, size_t size);
 void fav_destroy(fav_handle* h);
 const char* fav_last_error(const fav_handle* h); /* h may be NULL: error of the last failed fav_create */
 int32_t fav_abi_version(void);
@@ -176,6 +179,23 @@ fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems_per_fram
 fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t num_classes, int32_t ld,
                        float temperature, int32_t conf_kind, float tau,
                        int32_t* labels, float* conf, uint8_t* fail, float* score, void* hip_stream);
+
+/* ---- SignalAnalyzer.analyze_frame as one fused pass per frame (SURVEY.md §8f row 2;
+ * reference platform/backend/signal_analyzer.py:62-112): cv2.COLOR_BGR2GRAY, cv2.Laplacian
+ * (ksize 1, reflect-101) variance, mean brightness, mean |gray - previous gray|, 256-bin
+ * histogram entropy.  frames_bgr: [n][H][W][3] uint8 on the device, consecutive frames of
+ * one stream; prev_gray: gray plane preceding frame 0 (NULL = none); last_gray_out: receives
+ * the gray plane of frame n-1 (NULL = not wanted).  W % 4 == 0, H*W <= 150000. */
+typedef struct fav_signal_stats {
+    double lap_var, mean, mean_diff;
+    float entropy;
+    int32_t has_prev;
+    int64_t sum_lap, sum_lap2;         /* exact integer sums the doubles are derived from */
+    uint32_t sum_gray, sum_absdiff;
+    uint32_t hist[256];
+} fav_signal_stats;
+fav_status fav_op_signal_stats(const uint8_t* frames_bgr, int32_t n, int32_t H, int32_t W, const uint8_t* prev_gray,
+                               uint8_t* last_gray_out, fav_signal_stats* stats_dev, void* hip_stream);
 
 #ifdef __cplusplus
 }

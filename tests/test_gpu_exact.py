@@ -84,3 +84,20 @@ def test_resnet50_exact_mc_dropout_small(r50_blob):
     _exact_case("resnet50", r50_blob[0], frames, first_index=5, hw=(96, 96), n_samples=3, dropout_policy="all_blocks",
                 dropout_p=0.1, seed=4, chunk_a=3, chunk_b=5, regroup_block=9)
     _exact_case("resnet50", r50_blob[0], frames, hw=(96, 96), n_samples=2, dropout_policy="layer4+fc", dropout_p=0.2, seed=11)
+
+
+def test_deep_ensemble_exact(r18_blob):
+    """BASELINE configs[3] mechanics: M independently seeded members, softmax averaged over
+    members by the same head that averages MC samples; logits [M][n][C] bit-exact per member."""
+    blobs = [r18_blob[0]] + [weights.make_synthetic("resnet18_cifar", seed=s)[0] for s in (2, 3)]
+    frames = synth.synthetic_frames_u8(16, 32, 32, seed=12)
+    be = Backend("resnet18_cifar", blobs, max_batch=16, math_mode="f32_exact")
+    labels, conf = be.classify(torch.from_numpy(frames).cuda())
+    lg = be.logits().cpu().numpy()
+    be.close()
+    assert lg.shape == (3, 16, 10)
+    ref = np.stack([O.classify(O.parse_blob(b), frames, O.ClassifyConfig(exact=True), return_logits=True)[2][0] for b in blobs])
+    assert np.array_equal(lg, ref)
+    ol, oc, _ = O.confidence_head(ref)
+    assert np.array_equal(labels.cpu().numpy(), ol)
+    np.testing.assert_allclose(conf.cpu().numpy(), oc, rtol=0, atol=3e-6)
