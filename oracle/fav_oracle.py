@@ -309,6 +309,7 @@ class OracleNet:
     def __init__(self, model: Model, exact: bool = False):
         self.m = model
         self.exact = exact
+        self.trace = None   # set to a list to record (layer, input, residual, relu, output) per convolution
         self.cfg = arch_cfg(model.arch)
         self.blocks = []
         idx = 1
@@ -322,9 +323,15 @@ class OracleNet:
         assert idx + 1 == len(model.layers)
         self.nb = len(self.blocks)
 
+    def _rec(self, L, x, res, relu, y):
+        if self.trace is not None:
+            self.trace.append((L, x, res, relu, y))
+        return y
+
     # -- stages -------------------------------------------------------------
     def stem(self, xn):
         y = epilogue(conv_acc(xn, self.m.layers[0], self.exact), self.m.layers[0].b)
+        self._rec(self.m.layers[0], xn, None, True, y)
         if self.cfg["stem"] == "imagenet":
             y = maxpool3x3s2(y)
         return y
@@ -333,10 +340,11 @@ class OracleNet:
         main, down = self.blocks[i]
         h = x
         for L in main[:-1]:
-            h = epilogue(conv_acc(h, L, self.exact), L.b)
-        idn = x if down is None else epilogue(conv_acc(x, down, self.exact), down.b, relu=False)
+            h = self._rec(L, h, None, True, epilogue(conv_acc(h, L, self.exact), L.b))
+        idn = x if down is None else self._rec(down, x, None, False, epilogue(conv_acc(x, down, self.exact), down.b, relu=False))
         L = main[-1]
-        return epilogue(conv_acc(h, L, self.exact), L.b, res=idn, keep=keep, scale=scale)
+        y = epilogue(conv_acc(h, L, self.exact), L.b, res=idn, keep=keep, scale=scale)
+        return self._rec(L, h, idn, True, y) if keep is None else y
 
     def pool(self, x, keep=None, scale=np.float32(1.0)):
         y = global_avgpool(x)

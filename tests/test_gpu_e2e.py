@@ -113,6 +113,34 @@ def test_resnet50_224_vs_oracle(r50_blob):
     be.close()
 
 
+def test_resnet50_every_layer_teacher_forced(r50_blob):
+    """Production (bf16 MFMA) kernels on the REAL network, layer by layer: every one of the 53
+    convolutions of ResNet-50 at 224x224 is launched on the oracle's own input for that layer
+    (so errors cannot compound) and must match the oracle's output to one bf16 ulp on < 1 % of
+    elements.  This isolates kernel correctness from the bf16 chaos of the end-to-end check."""
+    import ctypes as C
+    from failure_aware_vision_amd import _lib
+    from test_gpu_ops import run_conv, assert_one_ulp
+    blob, _ = r50_blob
+    model = O.parse_blob(blob)
+    net = O.OracleNet(model, exact=True)
+    net.trace = []
+    frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(5, 224, 224, seed=21), 3, seed=3)
+    xn = O.normalize_input(frames, (0.485, 0.456, 0.406), O.inv_std32((0.229, 0.224, 0.225)))
+    net.forward_logits(xn)
+    lib = _lib.load()
+    assert len(net.trace) == 53
+    checked = 0
+    for L, x, res, relu, y in net.trace:
+        if L.cin % 64 != 0:
+            continue                      # the 3-channel stem goes through im2col: covered by test_gpu_ops
+        got = run_conv(lib, x, L.w, L.b, res, L.stride, L.pad, relu=1 if relu else 0)
+        assert got.shape == y.shape
+        assert_one_ulp(got, y)
+        checked += 1
+    assert checked == 52
+
+
 def test_full_size_properties(r50_blob):
     """BASELINE headline shape (ResNet-50, 224x224, batch 256, MC-Dropout): properties
     that need no oracle run.  (a) determinism; (b) shard invariance: two half batches
