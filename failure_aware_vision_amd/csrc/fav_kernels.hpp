@@ -147,11 +147,12 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
 // not counted, and the kernel retires it itself (vmcnt(0) + barrier before the
 // stage is read).  M0 is saved/restored in the same statement (the compiler owns it).
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t srd, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    // M0 is written and read inside one statement and declared clobbered; the kernel uses
+    // no other M0 consumer (no builtin LDS-DMA, no s_movrel), so nothing needs restoring.
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
                  : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
-                 : "memory");
+                 : "memory", "m0");
 }
 
 struct ConvParams {
@@ -168,6 +169,7 @@ struct ConvParams {
     int K, nk;      // K = kh*kw*Cin, nk = K / BK
     int relu, out_f32;
     int tiles_m, tiles_n;
+    int stage_mid;  // issue a 64-deep step's DMA after its first MFMA group (3x3) or in front (1x1)
     DropParams drop;
 };
 
@@ -322,11 +324,14 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
 
     int cur = 0, nxt = NS - 1;  // stage being read / stage being filled
     for (int kt = 0; kt < p.nk; ++kt) {
-        if (kt + NS - 1 < p.nk) FAV_STAGE(nxt, kt + NS - 1);
+        if ((BK == 32 || !p.stage_mid) && kt + NS - 1 < p.nk) FAV_STAGE(nxt, kt + NS - 1);
         const unsigned char* As = smem + cur * STAGE_BYTES;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
+            // 64-deep steps: the next tile's DMA is issued after the first MFMA group so its
+            // address arithmetic runs under matrix work instead of in front of it
+            if (BK == 64 && kk == 1 && p.stage_mid && kt + NS - 1 < p.nk) FAV_STAGE(nxt, kt + NS - 1);
             uint4 fx[TM], fw[TN];
             const int ch = kk * 4 + fq;
 #pragma unroll
