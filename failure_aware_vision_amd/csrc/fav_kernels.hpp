@@ -281,16 +281,22 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
     const uint32_t lds_a = lds_base + wave_u * (AR * 1024);
     const uint32_t lds_b = lds_base + A_BYTES + wave_u * (BR * 1024);
     int tap_r = 0, tap_s = 0, c0 = 0;  // K-tile position: tap (r, s), channel offset
+    const bool has_taps = p.K != p.Cin || p.pad != 0 || p.stride != 1;  // uniform
 
 // Issue the LDS-DMA of K tile KT into stage BUF (asynchronous; retired by the
 // explicit vmcnt(0) in front of the barrier that ends the K step).
 #define FAV_STAGE(BUF, KT)                                                                              \
     do {                                                                                                \
         const uint32_t soff_a = (uint32_t)(((tap_r * p.W + tap_s) * p.Cin + c0) * 2);                   \
-        _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
-            const bool ok = (unsigned)(a_ih0[i] + tap_r) < (unsigned)p.H &&                             \
-                            (unsigned)(a_iw0[i] + tap_s) < (unsigned)p.W;                               \
-            lds_dma16(srd_a, ok ? a_voff[i] : OOB, soff_a, lds_a + (BUF) * STAGE_BYTES + i * 1024);     \
+        if (has_taps) {                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                            \
+                const bool ok = (unsigned)(a_ih0[i] + tap_r) < (unsigned)p.H &&                         \
+                                (unsigned)(a_iw0[i] + tap_s) < (unsigned)p.W;                           \
+                lds_dma16(srd_a, ok ? a_voff[i] : OOB, soff_a, lds_a + (BUF) * STAGE_BYTES + i * 1024); \
+            }                                                                                           \
+        } else { /* 1x1, no padding: a row is either always valid or always beyond M */               \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                              \
+                lds_dma16(srd_a, a_voff[i], soff_a, lds_a + (BUF) * STAGE_BYTES + i * 1024);            \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                  \
             lds_dma16(srd_b, b_voff[i], (uint32_t)((KT) * ROWB), lds_b + (BUF) * STAGE_BYTES + i * 1024); \
