@@ -325,8 +325,8 @@ void launch_avgpool(fav_handle* h, const void* x, void* y, int n, int HW, int C,
 
 void launch_entry_dropout(fav_handle* h, const void* x, void* out, long long elems, int n_out, const DropParams& dp,
                           hipStream_t s) {
-    const long long total = (elems / 16) * n_out;
-    Prof pr(h, s, FAV_K_DROPOUT, 0.0, 4.0 * (double)elems * n_out);
+    const long long total = (elems / 16) * std::min<long long>(dp.n_img, n_out);   // threads: one per cached chunk
+    Prof pr(h, s, FAV_K_DROPOUT, 0.0, 2.0 * (double)elems * (n_out + std::min<long long>(dp.n_img, n_out)));
     hipLaunchKernelGGL(entry_dropout_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)out,
                        elems / 16, n_out, dp);
 }

@@ -570,25 +570,32 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const uint4* __restrict__ 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void entry_dropout_kernel(const uint4* __restrict__ x, uint4* __restrict__ out,
                                                             long long chunks_per_frame, int n_out, DropParams drop) {
-    // chunk = 16 elements = two uint4
-    const long long total = chunks_per_frame * n_out;
+    // A thread owns one 16-element chunk of one cached frame and writes every sample t of it
+    // that falls in [v0, v0 + n_out): the cached tensor is read once, not once per sample.
+    const long long total = chunks_per_frame * drop.n_img;
+    const long long v_end = drop.v0 + n_out;
+    const int t_lo = (int)(drop.v0 / drop.n_img), t_hi = (int)((v_end - 1) / drop.n_img);
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const long long vl = idx / chunks_per_frame;
-        const uint32_t chunk = (uint32_t)(idx - vl * chunks_per_frame);
-        const long long v = drop.v0 + vl;
-        const uint4* src = x + ((v % drop.n_img) * chunks_per_frame + chunk) * 2;
+        const long long img = idx / chunks_per_frame;
+        const uint32_t chunk = (uint32_t)(idx - img * chunks_per_frame);
+        const uint4* src = x + idx * 2;
         const uint4 a0 = src[0], a1 = src[1];
-        const uint32_t keep = drop_keep16(drop, v, chunk);
         const uint32_t vw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        uint32_t o[8];
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const long long v = (long long)t * drop.n_img + img;
+            if (v < drop.v0 || v >= v_end) continue;
+            const uint32_t keep = drop_keep16(drop, v, chunk);
+            uint32_t o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float lo = ((keep >> (2 * j)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] & 0xFFFFu), drop.scale) : 0.f;
-            const float hi = ((keep >> (2 * j + 1)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] >> 16), drop.scale) : 0.f;
-            o[j] = pack_bf16x2(lo, hi);
+            for (int j = 0; j < 8; ++j) {
+                const float lo = ((keep >> (2 * j)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] & 0xFFFFu), drop.scale) : 0.f;
+                const float hi = ((keep >> (2 * j + 1)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] >> 16), drop.scale) : 0.f;
+                o[j] = pack_bf16x2(lo, hi);
+            }
+            uint4* dst = out + ((v - drop.v0) * chunks_per_frame + chunk) * 2;
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
         }
-        out[idx * 2] = make_uint4(o[0], o[1], o[2], o[3]);
-        out[idx * 2 + 1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
 }
 
