@@ -1065,4 +1065,15 @@ fav_status fav_op_signal_stats(const uint8_t* frames, int32_t n, int32_t H, int3
     return op_done(nullptr);
 }
 
+fav_status fav_op_corrupt(const uint8_t* frames, void* out, int32_t n, int32_t H, int32_t W, int32_t mode, float level,
+                          float gain, float sigma, uint64_t seed, int64_t first_index, void* stream) {
+    if (!frames || !out || n < 1 || H < 1 || W < 1 || mode < 0 || mode > 3) return op_done("fav_op_corrupt: bad argument");
+    CorruptParams cp;
+    cp.mode = mode; cp.level = level; cp.gain = gain; cp.sigma = sigma;
+    cp.seed_lo = (uint32_t)(seed & 0xFFFFFFFFull); cp.seed_hi = (uint32_t)(seed >> 32); cp.first_index = first_index;
+    hipLaunchKernelGGL(corrupt_kernel, dim3(grid_for((long long)n * H * W)), dim3(256), 0, (hipStream_t)stream, frames, out,
+                       n, H, W, cp);
+    return op_done(nullptr);
+}
+
 }  // extern "C"

@@ -832,3 +832,77 @@ __global__ __launch_bounds__(256) void signal_stats_kernel(const uint8_t* __rest
 }
 
 }  // namespace fav
+
+// ===========================================================================
+// On-device corruption generator.  The reference corrupts frames in
+// the browser with Math.random (platform/frontend/js/app.js:782-857; modes
+// platform/backend/vision_simulator.py:15); here the same four modes plus ImageNet-C style
+// Gaussian noise run on the device with a counter-based generator, so a corrupted test set is
+// a pure function of (seed, global frame index) and needs no host round trip:
+//   normal    : p' = clamp(rne(p * gain + n)),  n = (u - 0.5) * 255 * level, ONE u per pixel   (app.js:789-798)
+//   blank     : (2, 2, 4)                                                                      (app.js:820-822)
+//   corrupted : with probability 0.2 a pixel becomes (u1*255, 0, u2*255); six horizontal
+//               bars of height 2..14 blended towards (255, 0, 170) with alpha 0.4..0.9        (app.js:835-850)
+//   gaussian  : fp32 out = clamp(p/255 + sigma * N(0,1)), Box-Muller on Philox uniforms
+// Philox4x32-10, key = seed, counter = (pixel or pair index, global frame, stream, 0).
+// ===========================================================================
+namespace fav {
+
+struct CorruptParams {
+    int mode;            // 0 normal, 1 blank, 2 corrupted, 3 gaussian (fp32 out)
+    float level, gain;   // uniform-noise level [0,1]; brightness gain
+    float sigma;         // gaussian sigma on [0,1] pixels
+    uint32_t seed_lo, seed_hi;
+    long long first_index;
+};
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // 24-bit, exact
+__device__ __forceinline__ uint32_t clamp_u8_rne(float v) { return (uint32_t)__float2int_rn(fminf(fmaxf(v, 0.f), 255.f)); }
+
+__global__ __launch_bounds__(256) void corrupt_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, int n, int H,
+                                                      int W, CorruptParams cp) {
+    const long long npx = (long long)H * W, total = npx * n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long f = idx / npx;
+        const uint32_t px = (uint32_t)(idx - f * npx);
+        const uint32_t frame = (uint32_t)(cp.first_index + f);
+        const uint8_t* p = in + idx * 3;
+        const float c0 = p[0], c1 = p[1], c2 = p[2];
+        if (cp.mode == 3) {
+            float* o = (float*)out + idx * 3;
+            const uint4 a = philox4x32_10(make_uint4(px, frame, 3u, 0u), cp.seed_lo, cp.seed_hi);
+            const uint4 b = philox4x32_10(make_uint4(px, frame, 4u, 0u), cp.seed_lo, cp.seed_hi);
+            // Box-Muller: radius from (1 - u) in (0,1], angle 2*pi*u'
+            const float r0 = sqrtf(-2.0f * logf(1.0f - u01(a.x))), r1 = sqrtf(-2.0f * logf(1.0f - u01(a.z)));
+            const float t0 = 6.2831853071795864f * u01(a.y), t1 = 6.2831853071795864f * u01(a.w);
+            const float n0 = r0 * cosf(t0), n1 = r0 * sinf(t0), n2 = r1 * cosf(t1);
+            (void)b;
+            o[0] = fminf(fmaxf(c0 * (1.0f / 255.0f) + cp.sigma * n0, 0.f), 1.f);
+            o[1] = fminf(fmaxf(c1 * (1.0f / 255.0f) + cp.sigma * n1, 0.f), 1.f);
+            o[2] = fminf(fmaxf(c2 * (1.0f / 255.0f) + cp.sigma * n2, 0.f), 1.f);
+            continue;
+        }
+        uint8_t* o = (uint8_t*)out + idx * 3;
+        if (cp.mode == 1) { o[0] = 2; o[1] = 2; o[2] = 4; continue; }
+        const uint4 u = philox4x32_10(make_uint4(px, frame, (uint32_t)cp.mode, 0u), cp.seed_lo, cp.seed_hi);
+        float v0 = c0 * cp.gain, v1 = c1 * cp.gain, v2 = c2 * cp.gain;
+        if (cp.mode == 0) {
+            const float nz = (u01(u.x) - 0.5f) * 255.0f * cp.level;
+            v0 += nz; v1 += nz; v2 += nz;
+        } else {
+            if (u01(u.x) > 0.8f) { v0 = u01(u.y) * 255.0f; v1 = 0.f; v2 = u01(u.z) * 255.0f; }
+            const int y = (int)(px / (uint32_t)W);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const uint4 q = philox4x32_10(make_uint4((uint32_t)b, frame, 7u, 0u), cp.seed_lo, cp.seed_hi);
+                const float by = u01(q.x) * (float)H, bh = 2.0f + u01(q.y) * 12.0f, al = 0.4f + u01(q.z) * 0.5f;
+                if ((float)y >= floorf(by) && (float)y < floorf(by) + floorf(bh)) {
+                    v0 = v0 + (255.0f - v0) * al; v1 = v1 + (0.0f - v1) * al; v2 = v2 + (170.0f - v2) * al;
+                }
+            }
+        }
+        o[0] = (uint8_t)clamp_u8_rne(v0); o[1] = (uint8_t)clamp_u8_rne(v1); o[2] = (uint8_t)clamp_u8_rne(v2);
+    }
+}
+
+}  // namespace fav

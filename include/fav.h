@@ -197,6 +197,17 @@ typedef struct fav_signal_stats {
 fav_status fav_op_signal_stats(const uint8_t* frames_bgr, int32_t n, int32_t H, int32_t W, const uint8_t* prev_gray,
                                uint8_t* last_gray_out, fav_signal_stats* stats_dev, void* hip_stream);
 
+/* ---- On-device corruption generator: the reference's four vision modes
+ * (platform/backend/vision_simulator.py:15, painted at platform/frontend/js/app.js:782-857) and
+ * ImageNet-C style Gaussian noise, as a pure function of (seed, global frame index).
+ * frames: uint8 [n][H][W][3] on the device.  out: uint8 [n][H][W][3] for modes 0..2, fp32
+ * [n][H][W][3] in [0,1] for FAV_CORRUPT_GAUSSIAN. */
+typedef enum fav_corrupt_mode { FAV_CORRUPT_NORMAL = 0, FAV_CORRUPT_BLANK = 1, FAV_CORRUPT_GLITCH = 2,
+                                FAV_CORRUPT_GAUSSIAN = 3 } fav_corrupt_mode;
+fav_status fav_op_corrupt(const uint8_t* frames, void* out, int32_t n, int32_t H, int32_t W, int32_t mode,
+                          float noise_level, float brightness_gain, float gaussian_sigma, uint64_t seed,
+                          int64_t first_frame_index, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
