@@ -198,14 +198,19 @@ def _exact_lib():
             import subprocess
             subprocess.check_call(["make", "-C", os.path.dirname(os.path.abspath(__file__))])
         lib = ctypes.CDLL(path)
-        lib.fav_exact_conv_acc.restype = ctypes.c_int
-        lib.fav_exact_conv_acc.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 9
+        for fn in (lib.fav_exact_conv_acc, lib.fav_bf16mfma_conv_acc):
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 9
+        lib.fav_bf16mfma_replay.restype = None
+        lib.fav_bf16mfma_replay.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int]
         _EXACT_LIB = lib
     return _EXACT_LIB
 
 
-def conv_acc_exact(x: np.ndarray, w: np.ndarray, kh: int, kw: int, stride: int, pad: int) -> np.ndarray:
-    """Sequential-k fp32 accumulator (oracle/fav_exact.c).  x [B,H,W,C], w [N,kh,kw,C], C % 64 == 0."""
+def conv_acc_exact(x: np.ndarray, w: np.ndarray, kh: int, kw: int, stride: int, pad: int, mode=True) -> np.ndarray:
+    """Order-exact fp32 accumulator (oracle/fav_exact.c).  x [B,H,W,C], w [N,kh,kw,C], C % 64 == 0.
+    mode True  : k-ordered fmaf chain of the device's FAV_MATH_F32_EXACT mode;
+    mode "mfma": the bit-exact model of v_mfma_f32_16x16x32_bf16, i.e. the production mode."""
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
     b, h, ww, c = x.shape
@@ -213,7 +218,8 @@ def conv_acc_exact(x: np.ndarray, w: np.ndarray, kh: int, kw: int, stride: int, 
     ho = (h + 2 * pad - kh) // stride + 1
     wo = (ww + 2 * pad - kw) // stride + 1
     out = np.empty((b, ho, wo, n), np.float32)
-    rc = _exact_lib().fav_exact_conv_acc(x.ctypes.data, w.ctypes.data, out.ctypes.data, b, h, ww, c, n, kh, kw, stride, pad)
+    fn = _exact_lib().fav_bf16mfma_conv_acc if mode == "mfma" else _exact_lib().fav_exact_conv_acc
+    rc = fn(x.ctypes.data, w.ctypes.data, out.ctypes.data, b, h, ww, c, n, kh, kw, stride, pad)
     if rc != 0:
         raise RuntimeError(f"fav_exact_conv_acc failed ({rc})")
     return out
@@ -230,7 +236,7 @@ def conv_acc(x: np.ndarray, L: ConvLayer, exact: bool = False) -> np.ndarray:
         acc = cols @ L.w.reshape(L.cout, -1).T
         return acc.reshape(x.shape[0], ho, wo, L.cout).astype(np.float32)
     if L.cin % 64 == 0:
-        return conv_acc_exact(x, L.w, L.kh, L.kw, L.stride, L.pad)
+        return conv_acc_exact(x, L.w, L.kh, L.kw, L.stride, L.pad, exact)
     cols, ho, wo = _im2col(x, L.kh, L.kw, L.stride, L.pad)
     k = cols.shape[1]
     kpad = (k + 63) // 64 * 64
@@ -238,7 +244,7 @@ def conv_acc(x: np.ndarray, L: ConvLayer, exact: bool = False) -> np.ndarray:
     a1[..., :k] = cols.reshape(x.shape[0], ho, wo, k)
     wp = np.zeros((L.cout, 1, 1, kpad), np.float32)
     wp[:, 0, 0, :k] = L.w.reshape(L.cout, k)
-    return conv_acc_exact(a1, wp, 1, 1, 1, 0)
+    return conv_acc_exact(a1, wp, 1, 1, 1, 0, exact)
 
 
 def epilogue(acc, bias, res=None, relu=True, keep=None, scale=np.float32(1.0)) -> np.ndarray:
@@ -354,7 +360,7 @@ class OracleNet:
 
     def logits(self, feat):
         if self.exact:
-            acc = conv_acc_exact(feat[:, None, None, :], self.fc.w, 1, 1, 1, 0)[:, 0, 0, :]
+            acc = conv_acc_exact(feat[:, None, None, :], self.fc.w, 1, 1, 1, 0, self.exact)[:, 0, 0, :]
             return acc + self.fc.b
         return (feat @ self.fc.w.reshape(self.fc.cout, -1).T).astype(np.float32) + self.fc.b
 
@@ -472,7 +478,8 @@ class ClassifyConfig:
     temperature: float = 1.0
     conf_kind: int = CONF_MAX_SOFTMAX
     tau: float = 0.5
-    exact: bool = False   # reproduce the device's FAV_MATH_F32_EXACT mode bit for bit
+    exact: object = False   # True: reproduce the device's FAV_MATH_F32_EXACT mode bit for bit;
+                            # "mfma": reproduce the production bf16-MFMA mode bit for bit
 
 
 def inv_std32(std):

@@ -42,16 +42,38 @@ def test_conv_exact_bitwise(lib, cin, cout, k, stride, pad, H, W, n):
     assert np.array_equal(got2, O.epilogue(acc, b, res=res, relu=True))
 
 
-def _exact_case(arch, blob, frames, first_index=0, hw=None, **kw):
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,n,use_res", [
+    (64, 64, 1, 1, 0, 14, 14, 3, False), (64, 128, 3, 2, 1, 15, 15, 2, True), (128, 256, 3, 1, 1, 9, 9, 2, False),
+    (512, 128, 1, 1, 0, 7, 7, 3, True), (192, 64, 1, 1, 0, 16, 16, 2, False),
+    (128, 256, 3, 1, 1, 30, 30, 19, False),   # 256x256 tile, 64-deep steps
+    (512, 256, 1, 1, 0, 30, 30, 19, False),   # 256x256 tile on a 1x1
+    (64, 64, 3, 1, 1, 56, 56, 2, True),       # 128x64 tile
+])
+def test_conv_production_mode_bitwise(lib, cin, cout, k, stride, pad, H, W, n, use_res):
+    """The PRODUCTION kernels (bf16 MFMA) against the bit-exact model of the instruction
+    (oracle/fav_exact.c: mfma_step8): same bits, for every tile shape and K depth."""
+    rng = np.random.default_rng(cin * 7 + cout + k)
+    x = O.bf16_round(np.maximum(rng.standard_normal((n, H, W, cin)) * np.exp2(rng.integers(-2, 3, (n, H, W, cin))), -0.3).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32))
+    b = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    acc = O.conv_acc_exact(x, w, k, k, stride, pad, mode="mfma")
+    got = run_conv(lib, x, w, b, None, stride, pad, relu=0, out_f32=1, math_mode=0)
+    assert np.array_equal(got, acc + b), f"{np.mean(got != acc + b):.5f} of elements differ"
+    res = O.bf16_round(rng.standard_normal(acc.shape).astype(np.float32)) if use_res else None
+    got2 = run_conv(lib, x, w, b, res, stride, pad, relu=1, math_mode=0)
+    assert np.array_equal(got2, O.epilogue(acc, b, res=res, relu=True))
+
+
+def _exact_case(arch, blob, frames, first_index=0, hw=None, math="f32_exact", **kw):
     model = O.parse_blob(blob)
     aid = weights.ARCH_IDS[arch]
     policy = kw.get("dropout_policy", "none")
     T = kw.get("n_samples", 1)
-    be = Backend(arch, blob, max_batch=frames.shape[0], math_mode="f32_exact", in_hw=hw, **kw)
+    be = Backend(arch, blob, max_batch=frames.shape[0], math_mode=math, in_hw=hw, **kw)
     labels, conf = be.classify(torch.from_numpy(frames).cuda(), first_index=first_index)
     lg = be.logits().cpu().numpy()
     ocfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(aid, policy), p=kw.get("dropout_p", 0.0),
-                            seed=kw.get("seed", 0), exact=True,
+                            seed=kw.get("seed", 0), exact=True if math == "f32_exact" else "mfma",
                             conf_kind=O.CONF_ENTROPY if kw.get("conf_kind") == "entropy" else O.CONF_MAX_SOFTMAX)
     ids = np.arange(first_index, first_index + frames.shape[0])
     ol, oc, olg, opb = O.classify(model, frames, ocfg, img_ids=ids, return_logits=True)
@@ -101,3 +123,25 @@ def test_deep_ensemble_exact(r18_blob):
     ol, oc, _ = O.confidence_head(ref)
     assert np.array_equal(labels.cpu().numpy(), ol)
     np.testing.assert_allclose(conf.cpu().numpy(), oc, rtol=0, atol=3e-6)
+
+
+# ---- the production mode itself, bit for bit ----------------------------------------------
+
+def test_resnet18_production_mode_bitwise(r18_blob):
+    """FAV_MATH_BF16 end to end against the oracle running the bit-exact MFMA model: logits
+    bit-identical, labels exactly equal — no tolerance."""
+    _exact_case("resnet18_cifar", r18_blob[0], synth.synthetic_frames_u8(16, 32, 32, seed=7), math="bf16")
+
+
+@pytest.mark.parametrize("policy", ["last_layer", "layer4+fc", "all_blocks"])
+def test_resnet18_production_mode_mc_dropout_bitwise(r18_blob, policy):
+    _exact_case("resnet18_cifar", r18_blob[0], synth.synthetic_frames_u8(6, 32, 32, seed=8), first_index=123, math="bf16",
+                n_samples=3, dropout_policy=policy, dropout_p=0.1, seed=4, conf_kind="entropy", chunk_a=5, chunk_b=7)
+
+
+def test_resnet50_production_mode_bitwise(r50_blob):
+    frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(2, 224, 224, seed=7), 3, seed=3)
+    _exact_case("resnet50", r50_blob[0], frames, math="bf16")
+    small = synth.synthetic_frames_u8(3, 64, 64, seed=9)
+    _exact_case("resnet50", r50_blob[0], small, first_index=5, hw=(64, 64), math="bf16", n_samples=2,
+                dropout_policy="all_blocks", dropout_p=0.1, seed=4)

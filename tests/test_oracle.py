@@ -165,3 +165,25 @@ def test_blob_is_machine_independent(r18_blob, r50_blob):
     pinned = json.load(open(path))
     assert r18_blob[1]["sha256"] == pinned["resnet18_cifar_seed1"]
     assert r50_blob[1]["sha256"] == pinned["resnet50_seed1"]
+
+
+def test_bf16_mfma_model_reproduces_recorded_instruction_outputs():
+    """oracle/fav_exact.c models v_mfma_f32_16x16x32_bf16 (the instruction the production kernels
+    accumulate with).  tests/golden/mfma_kat.npz holds raw outputs of that instruction recorded on an
+    MI355X (tools/mfma_probe*.py: random, wide-range, sparse, accumulator-dominant, carry-out and
+    leading-bit-loss operands); the model must reproduce every one bit for bit."""
+    import ctypes
+    import os
+    lib = O._exact_lib()
+    kat = np.load(os.path.join(os.path.dirname(__file__), "golden", "mfma_kat.npz"))
+    names = sorted(set(k[:-2] for k in kat.files))
+    assert len(names) >= 40
+    total = 0
+    for n in names:
+        tof = lambda b: np.ascontiguousarray((b.astype(np.uint32) << 16).view(np.float32))
+        A, B, C, D = tof(kat[n + "_A"]), tof(kat[n + "_B"]), np.ascontiguousarray(kat[n + "_C"]), kat[n + "_D"]
+        out = np.empty_like(D)
+        lib.fav_bf16mfma_replay(A.ctypes.data, B.ctypes.data, C.ctypes.data, out.ctypes.data, A.shape[0])
+        assert np.array_equal(out, D), n
+        total += D.size
+    assert total > 100000
