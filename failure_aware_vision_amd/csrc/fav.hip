@@ -170,6 +170,7 @@ DropParams make_drop(const fav_dropout_desc* d) {
     DropParams p;
     if (!d || d->site < 0) {
         p.site = -1; p.thr = 0; p.scale = 1.f; p.seed_lo = p.seed_hi = 0; p.v0 = 0; p.n_img = 1; p.first_index = 0;
+        p.div_img = fastdiv_make(1);
         return p;
     }
     p.site = d->site;
@@ -180,6 +181,7 @@ DropParams make_drop(const fav_dropout_desc* d) {
     p.v0 = d->v0;
     p.n_img = d->n_img > 0 ? d->n_img : 1;
     p.first_index = d->first_image_index;
+    p.div_img = fastdiv_make((uint32_t)p.n_img);
     return p;
 }
 
@@ -241,6 +243,9 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     p.K = d.kh * d.kw * d.Cin; p.nk = p.K / 64;
     p.relu = d.relu; p.out_f32 = d.out_f32;
     p.drop = make_drop(&d.drop);
+    p.div_hwo = fastdiv_make((uint32_t)p.HWo);
+    if (p.drop.site >= 0 && (p.drop.v0 < 0 || p.drop.v0 + d.n_frames > 0x7fffffffLL)) return "conv: virtual frame index out of range";
+    p.dbg = nullptr;
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
     const bool big = conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
@@ -262,6 +267,8 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const double flops = 2.0 * (double)M * d.Cout * p.K;
     const double bytes = 2.0 * ((double)d.n_frames * d.H * d.W * d.Cin + (double)M * d.Cout * (d.res ? 2 : 1) * (d.out_f32 ? 2 : 1)
                                 + (double)d.Cout * p.K);
+    static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
+    if (dbg_on && !h) (void)hipMalloc((void**)&p.dbg, (size_t)tiles * 32);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
     dim3 grid((unsigned)tiles);
     p.nk = p.K / BK;
@@ -286,12 +293,30 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 #undef FAV_LAUNCH_MODE
 #undef FAV_LAUNCH_NS
 #undef FAV_LAUNCH
+    if (p.dbg) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> t((size_t)tiles * 4);
+        (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(p.dbg);
+        unsigned long long lo = ~0ull, hi = 0;
+        double ph[3] = {0, 0, 0};
+        for (long long i = 0; i < tiles; ++i) {
+            lo = std::min(lo, t[i * 4]); hi = std::max(hi, t[i * 4 + 3]);
+            for (int j = 0; j < 3; ++j) ph[j] += (double)(t[i * 4 + j + 1] - t[i * 4 + j]);
+        }
+        const double span = (double)(hi - lo), life = ph[0] + ph[1] + ph[2];
+        fprintf(stderr, "[conv dbg] tiles %lld BMxBNxBK %dx%dx%d span %.1f us; per block: prologue %.2f us, k-loop %.2f us, epilogue %.2f us; "
+                        "resident blocks/CU %.2f\n", tiles, BM, BN, BK, span / 100.0, ph[0] / tiles / 100.0, ph[1] / tiles / 100.0,
+                ph[2] / tiles / 100.0, life / span / 256.0);
+    }
     return nullptr;
 }
 
+// One work item per thread whenever the grid allows (grid-stride loops only catch the rest): on gfx9
+// stores count in vmcnt, so a second iteration's loads would wait for the first iteration's stores.
 unsigned grid_for(long long work_items) {
     long long g = (work_items + 255) / 256;
-    return (unsigned)std::max<long long>(1, std::min<long long>(g, 256 * 16));
+    return (unsigned)std::max<long long>(1, std::min<long long>(g, (1ll << 24) - 1));
 }
 
 void launch_stem(fav_handle* h, const void* images, int layout, int n, int H, int W, int kh, int kw, int stride, int pad,

@@ -29,6 +29,7 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
 // same result as the integer recipe above for every finite input)
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
@@ -48,6 +49,22 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
+// Exact unsigned division by a launch constant (Granlund-Montgomery): for n < 2^31,
+// n / d == (umulhi(n, magic) + n) >> shift.  Host side: fastdiv_make().
+struct FastDiv {
+    uint32_t magic, shift, d;
+};
+inline FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.magic = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.shift = l;
+    f.d = d;
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) { return (__umulhi(n, f.magic) + n) >> f.shift; }
+
 struct DropParams {
     int site;                 // -1: none
     uint32_t thr;             // 8-bit threshold: drop iff draw < thr
@@ -56,23 +73,24 @@ struct DropParams {
     long long v0;             // virtual frame index of row 0 (v = t * n_img + i)
     int n_img;                // frames per sample
     long long first_index;    // global index of frame 0
+    FastDiv div_img;          // / n_img (virtual frame indices of one launch stay below 2^31)
 };
 
-// 16-bit keep mask for the 16 elements of chunk `chunk` (= element_index / 16) of
-// virtual frame v: one Philox call = 16 bytes = 16 draws, byte j (little endian over
-// the four output words) belongs to element 16*chunk + j.
-__device__ __forceinline__ uint32_t drop_keep16(const DropParams& d, long long v, uint32_t chunk) {
-    const uint32_t t = (uint32_t)(v / d.n_img);
-    const uint32_t img = (uint32_t)(d.first_index + (v % d.n_img));
-    const uint4 w = philox4x32_10(make_uint4(chunk, img, t, (uint32_t)d.site), d.seed_lo, d.seed_hi);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-    uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) m |= (uint32_t)(((ww[q] >> (8 * b)) & 0xFFu) >= d.thr) << (4 * q + b);
-    return m;
+// The 16 draws (bytes, little endian over the four words) of chunk `chunk` (= element_index / 16)
+// of virtual frame v (< 2^31); element 16*chunk + j is KEPT iff byte j >= d.thr.
+__device__ __forceinline__ uint4 drop_draws16(const DropParams& d, uint32_t v, uint32_t chunk) {
+    const uint32_t t = fastdiv(v, d.div_img);
+    const uint32_t img = (uint32_t)d.first_index + (v - t * (uint32_t)d.n_img);
+    return philox4x32_10(make_uint4(chunk, img, t, (uint32_t)d.site), d.seed_lo, d.seed_hi);
 }
+
+// Same draws when the sample t and the frame's index inside the launch are already known.
+__device__ __forceinline__ uint4 drop_draws16_ti(const DropParams& d, uint32_t t, uint32_t img_local, uint32_t chunk) {
+    return philox4x32_10(make_uint4(chunk, (uint32_t)d.first_index + img_local, t, (uint32_t)d.site), d.seed_lo, d.seed_hi);
+}
+// v = keep(byte j of the draws) ? v * scale : 0
+#define FAV_DROP_APPLY(V, DRAWS, J, D) \
+    ((((DRAWS)[(J) >> 2] >> (8 * ((J) & 3))) & 0xFFu) >= (D).thr ? __fmul_rn((V), (D).scale) : 0.f)
 
 // ---------------------------------------------------------------------------
 // Stem: frames (u8 / fp32 NHWC3) -> normalised bf16 im2col rows [n*Ho*Wo][kpad]
@@ -171,6 +189,8 @@ struct ConvParams {
     int tiles_m, tiles_n;
     int stage_mid;  // issue a 64-deep step's DMA after its first MFMA group (3x3) or in front (1x1)
     DropParams drop;
+    FastDiv div_hwo;  // / HWo
+    unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
 };
 
 // LDS swizzle of a staged K tile: rows are BK*2 bytes, a row holds BK/8 16-B chunks.
@@ -187,9 +207,10 @@ __device__ __forceinline__ int lds_swz(int row) {
 // waves per SIMD the LDS footprint allows (what __launch_bounds__ should ask for)
 constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
     const int stage = NS * (BM + BN) * BK * 2, out = 64 * (BN + 4) * 4;
-    const int lds = stage > out ? stage : out;
+    const int lds = (stage > out ? stage : out) + BN * 4;
     int blocks = 163840 / lds;
     if (blocks > 4) blocks = 4;
+    if (BN >= 128 && blocks > 3) blocks = 3;  // 64 accumulators + the prefetched residual need > 128 VGPRs
     if (blocks < 1) blocks = 1;
     return blocks * (BM * 2 / 64) / 4;
 }
@@ -209,12 +230,13 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
     constexpr int OUT_BYTES = 64 * OUT_LD * 4;  // the epilogue stages 64 rows (one wave row) at a time
     constexpr int LDS_BYTES = (NS * STAGE_BYTES > OUT_BYTES) ? NS * STAGE_BYTES : OUT_BYTES;
     constexpr int AR = A_BYTES / 1024 / NWAVES, BR = B_BYTES / 1024 / NWAVES;  // LDS-DMA pieces per wave per tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BN * 4];  // + this tile's bias
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
 
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (L2); give each XCD a
     // contiguous run of tiles, n fastest, so the A tile of one m is re-read from
@@ -228,6 +250,50 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
     const int tile_n = tile % p.tiles_n;
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // The tile's bias goes to LDS now: on gfx9 stores count in vmcnt like loads, so ANY global
+    // load inside the epilogue would wait for every store issued before it (a full write
+    // round trip per pass).  The epilogue therefore issues all its loads before its first store.
+    if (tid < BN) ((float*)(smem + LDS_BYTES))[tid] = p.bias[n0 + tid];
+
+    // ---- epilogue geometry, and the residual prefetch -------------------------------
+    // A thread finishes 16 consecutive channels of one output pixel per pass.  The residual
+    // rows of the WHOLE tile are requested here, in front of the K loop: their latency hides
+    // under it and no load is left to issue once the stores begin.  Tiles whose residual
+    // would not fit in registers (256 x 256) fetch it one 64-row group at a time instead.
+    constexpr int NCH = BN / 16;           // 16-channel chunks per row
+    constexpr int RPP = (NT / NCH > 64) ? 64 : NT / NCH;  // rows per pass (threads beyond 64 rows idle)
+    constexpr int NPASS = 64 / RPP;        // passes per 64-row group
+    constexpr int NGROUPS = BM / 64;
+    const int ec = tid % NCH, er = tid / NCH;
+    const int n = n0 + ec * 16;
+    const float* bias_s = (const float*)(smem + LDS_BYTES) + ec * 16;
+    constexpr bool RES_ALL = NGROUPS * NPASS * 2 <= 8;
+    constexpr int RG = RES_ALL ? NGROUPS : 1;
+    u32x4_t rres[RG][NPASS][2];
+#define FAV_LOAD_RES(G, HALF)                                                              \
+    _Pragma("unroll") for (int pass = 0; pass < NPASS; ++pass) {                           \
+        const int m = m0 + (HALF) * 64 + er + pass * RPP;                                  \
+        if (er < 64 && m < p.M && n < p.Cout) {                                            \
+            const u32x4_t* rp = (const u32x4_t*)(p.res + (long long)m * p.ldy + n);        \
+            rres[G][pass][0] = rp[0];                                                      \
+            rres[G][pass][1] = rp[1];                                                      \
+        }                                                                                  \
+    }
+// Empty asm that "redefines" the residual registers: the compiler puts its one wait for the
+// loads in front of it and forgets them afterwards, so later uses (after stores have been
+// issued) do not turn into waits for those stores.
+#define FAV_RES_LANDED()                                                                   \
+    _Pragma("unroll") for (int g_ = 0; g_ < RG; ++g_)                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < NPASS; ++q_)                               \
+            asm volatile("" : "+v"(rres[g_][q_][0]), "+v"(rres[g_][q_][1]))
+#pragma unroll
+    for (int g_ = 0; g_ < RG; ++g_)
+#pragma unroll
+        for (int q_ = 0; q_ < NPASS; ++q_) rres[g_][q_][0] = rres[g_][q_][1] = (u32x4_t){0u, 0u, 0u, 0u};
+    if (RES_ALL && p.res) {
+#pragma unroll
+        for (int g = 0; g < NGROUPS; ++g) FAV_LOAD_RES(g, g)
+    }
 
     // ---- per-lane gather descriptors ------------------------------------------
     // Tiles are staged with LDS-DMA: one wave instruction writes 1 KiB = PROWS rows x
@@ -327,6 +393,7 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
     if (p.nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 1] = wall_clock64();
 
     int cur = 0, nxt = NS - 1;  // stage being read / stage being filled
     for (int kt = 0; kt < p.nk; ++kt) {
@@ -396,27 +463,13 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
     // BEFORE the accumulators go through LDS so their latency hides behind the staging
     // barrier.  (The barrier that ended the K loop already separates the last fragment
     // reads from the first staging writes.)
-    constexpr int NCH = BN / 16;           // 16-channel chunks per row
-    constexpr int RPP = (NT / NCH > 64) ? 64 : NT / NCH;  // rows per pass (threads beyond 64 rows idle)
-    constexpr int NPASS = 64 / RPP;        // passes per 64-row group
-    constexpr int NGROUPS = BM / 64;
-    const int ec = tid % NCH, er = tid / NCH;
-    const int n = n0 + ec * 16;
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 2] = wall_clock64();
     float* outs = (float*)smem;
+    FAV_RES_LANDED();
 #pragma unroll
     for (int half = 0; half < NGROUPS; ++half) {
-        uint4 rres[NPASS][2];
-        if (p.res) {
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int m = m0 + half * 64 + er + pass * RPP;
-                if (er < 64 && m < p.M && n < p.Cout) {
-                    const uint4* rp = (const uint4*)(p.res + (long long)m * p.ldy + n);
-                    rres[pass][0] = rp[0];
-                    rres[pass][1] = rp[1];
-                }
-            }
-        }
+        const int rg = RES_ALL ? half : 0;
+        if (!RES_ALL && p.res) FAV_LOAD_RES(0, half)
         if (half > 0) __syncthreads();  // everyone is done reading the previous group
         if (wm == half) {
 #pragma unroll
@@ -429,17 +482,19 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
                 }
         }
         __syncthreads();
+        if (!RES_ALL) FAV_RES_LANDED();
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int ml = er + pass * RPP;
             const int m = m0 + half * 64 + ml;
             if (er >= 64 || m >= p.M || n >= p.Cout) continue;
-            uint32_t keep = 0xFFFFu;
+            uint32_t draws[4] = {~0u, ~0u, ~0u, ~0u};  // all-ones bytes: always kept
             if (!p.out_f32 && p.drop.site >= 0) {
-                const int vl = m / p.HWo;
-                const int pix = m - vl * p.HWo;
+                const uint32_t vl = fastdiv((uint32_t)m, p.div_hwo);
+                const uint32_t pix = (uint32_t)m - vl * (uint32_t)p.HWo;
                 const uint32_t chunk = (uint32_t)(((long long)pix * p.Cout + n) >> 4);
-                keep = drop_keep16(p.drop, p.drop.v0 + vl, chunk);
+                const uint4 w = drop_draws16(p.drop, (uint32_t)p.drop.v0 + vl, chunk);
+                draws[0] = w.x; draws[1] = w.y; draws[2] = w.z; draws[3] = w.w;
             }
             // the 16 channels in two groups of 8 (keeps the live register set small)
 #pragma unroll
@@ -448,12 +503,12 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const float4 t4 = *(const float4*)(outs + ml * OUT_LD + ec * 16 + 8 * g + 4 * q);
-                    const float4 bq = *(const float4*)(p.bias + n + 8 * g + 4 * q);
+                    const float4 bq = *(const float4*)(bias_s + 8 * g + 4 * q);
                     v[4 * q] = __fadd_rn(t4.x, bq.x); v[4 * q + 1] = __fadd_rn(t4.y, bq.y);
                     v[4 * q + 2] = __fadd_rn(t4.z, bq.z); v[4 * q + 3] = __fadd_rn(t4.w, bq.w);
                 }
                 if (p.res) {
-                    const uint32_t rw[4] = {rres[pass][g].x, rres[pass][g].y, rres[pass][g].z, rres[pass][g].w};
+                    const uint32_t rw[4] = {rres[rg][pass][g][0], rres[rg][pass][g][1], rres[rg][pass][g][2], rres[rg][pass][g][3]};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[2 * j] = __fadd_rn(v[2 * j], bf16_bits_to_f32(rw[j] & 0xFFFFu));
@@ -474,7 +529,7 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
                     if (p.drop.site >= 0) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            v[j] = ((keep >> (8 * g + j)) & 1u) ? __fmul_rn(v[j], p.drop.scale) : 0.f;
+                            v[j] = FAV_DROP_APPLY(v[j], draws, 8 * g + j, p.drop);
                     }
                     *(uint4*)((uint16_t*)p.y + (long long)m * p.ldy + n + 8 * g) =
                         make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
@@ -483,9 +538,15 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
             }
         }
     }
+    if (p.dbg) {
+        __syncthreads();
+        if (tid == 0) p.dbg[blockIdx.x * 4ull + 3] = wall_clock64();
+    }
 }
 
 #undef FAV_STAGE
+#undef FAV_LOAD_RES
+#undef FAV_RES_LANDED
 
 // ---------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max pool, NHWC bf16; one thread = 8 channels of one output
@@ -552,9 +613,10 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const uint4* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = __fmul_rn(acc[j], inv_hw);
         if (drop.site >= 0) {
-            const uint32_t keep = drop_keep16(drop, drop.v0 + img, (uint32_t)c);
+            const uint4 w = drop_draws16(drop, (uint32_t)(drop.v0 + img), (uint32_t)c);
+            const uint32_t draws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = ((keep >> j) & 1u) ? __fmul_rn(acc[j], drop.scale) : 0.f;
+            for (int j = 0; j < 16; ++j) acc[j] = FAV_DROP_APPLY(acc[j], draws, j, drop);
         }
         y[idx * 2] = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
                                 pack_bf16x2(acc[6], acc[7]));
@@ -584,12 +646,13 @@ __global__ __launch_bounds__(256) void entry_dropout_kernel(const uint4* __restr
         for (int t = t_lo; t <= t_hi; ++t) {
             const long long v = (long long)t * drop.n_img + img;
             if (v < drop.v0 || v >= v_end) continue;
-            const uint32_t keep = drop_keep16(drop, v, chunk);
+            const uint4 w = drop_draws16_ti(drop, (uint32_t)t, (uint32_t)img, chunk);
+            const uint32_t draws[4] = {w.x, w.y, w.z, w.w};
             uint32_t o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float lo = ((keep >> (2 * j)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] & 0xFFFFu), drop.scale) : 0.f;
-                const float hi = ((keep >> (2 * j + 1)) & 1u) ? __fmul_rn(bf16_bits_to_f32(vw[j] >> 16), drop.scale) : 0.f;
+                const float lo = FAV_DROP_APPLY(bf16_bits_to_f32(vw[j] & 0xFFFFu), draws, 2 * j, drop);
+                const float hi = FAV_DROP_APPLY(bf16_bits_to_f32(vw[j] >> 16), draws, 2 * j + 1, drop);
                 o[j] = pack_bf16x2(lo, hi);
             }
             uint4* dst = out + ((v - drop.v0) * chunks_per_frame + chunk) * 2;

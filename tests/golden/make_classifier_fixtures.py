@@ -4,8 +4,10 @@ the fixtures hold only expected outputs.
 
   python tests/golden/make_classifier_fixtures.py mc      # 64 frames, T=30 all_blocks  (~10 min on 8 cores)
   python tests/golden/make_classifier_fixtures.py 10k     # 10,000 frames, single pass  (~1 h on 8 cores)
+  python tests/golden/make_classifier_fixtures.py mfma_mc # 16 frames, T=30 all_blocks, production bf16-MFMA model
+  python tests/golden/make_classifier_fixtures.py mfma_1k # 1,000 frames, single pass, production bf16-MFMA model
 """
-import os, sys, time
+import os, sys, time, zlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -21,6 +23,12 @@ model = O.parse_blob(blob)
 def frames(start, n):
     u8 = synth.synthetic_frames_u8(n, 224, 224, seed=FRAME_SEED, start_id=start)
     return synth.gaussian_noise_f32(u8, SEVERITY, seed=NOISE_SEED, start_id=start)
+
+
+def frame_crc(lg):
+    """zlib.crc32 of each frame's fp32 logits [T, classes] (little endian, t-major)."""
+    lg = np.asarray(lg, np.float32)
+    return np.array([zlib.crc32(np.ascontiguousarray(lg[:, i, :]).tobytes()) for i in range(lg.shape[1])], np.uint32)
 
 
 def gap_of(pbar):
@@ -41,6 +49,42 @@ if what == "mc":
     np.savez_compressed(os.path.join(HERE, "r50_exact_mc30_64.npz"), labels=np.concatenate(labels).astype(np.int16),
                         conf=np.concatenate(conf), gap=np.concatenate(gaps), blob_sha256=info["sha256"],
                         meta="resnet50 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; exact")
+elif what == "mfma_mc":
+    n, T = 16, 30
+    cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact="mfma")
+    labels, conf, gaps, logits = [], [], [], []
+    for s in range(0, n, 4):
+        t0 = time.time()
+        l, c, lg, pb = O.classify(model, frames(s, 4), cfg, img_ids=np.arange(s, s + 4), return_logits=True)
+        labels.append(l); conf.append(c); gaps.append(gap_of(pb)); logits.append(frame_crc(lg))
+        print("mfma_mc", s, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "r50_mfma_mc30_16.npz"), labels=np.concatenate(labels).astype(np.int16),
+                        conf=np.concatenate(conf), gap=np.concatenate(gaps), logit_crc32=np.concatenate(logits),
+                        blob_sha256=info["sha256"],
+                        meta="resnet50 seed1; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; "
+                             "production mode (v_mfma_f32_16x16x32_bf16 model)")
+elif what == "mfma_1k":
+    n, bs = 1000, 20
+    part = os.path.join(HERE, "_mfma1k_partial.npz")
+    done = 0
+    labels = np.zeros(n, np.int16); conf = np.zeros(n, np.float32); gaps = np.zeros(n, np.float32)
+    lsum = np.zeros(n, np.uint32)
+    if os.path.exists(part):
+        d = np.load(part); done = int(d["done"]); labels, conf, gaps, lsum = d["labels"], d["conf"], d["gap"], d["lsum"]
+    cfg = O.ClassifyConfig(exact="mfma")
+    t0 = time.time()
+    for s in range(done, n, bs):
+        l, c, lg, pb = O.classify(model, frames(s, bs), cfg, return_logits=True)
+        labels[s:s + bs] = l; conf[s:s + bs] = c; gaps[s:s + bs] = gap_of(pb)
+        lsum[s:s + bs] = frame_crc(lg)
+        np.savez(part, done=s + bs, labels=labels, conf=conf, gap=gaps, lsum=lsum)
+        print("mfma_1k", s + bs, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "r50_mfma_1k_noise3.npz"), labels=labels, conf=conf, gap=gaps, logit_crc32=lsum,
+                        blob_sha256=info["sha256"],
+                        meta="resnet50 seed1; frames seed 21 ids 0..999 + gaussian noise sev3 seed 3; single pass; "
+                             "production mode (v_mfma_f32_16x16x32_bf16 model); logit_crc32 = zlib.crc32 of each frame's fp32 logits")
+    if os.path.exists(part):
+        os.remove(part)
 else:
     n, bs = 10000, 50
     part = os.path.join(HERE, "_10k_partial.npz")

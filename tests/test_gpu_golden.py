@@ -4,11 +4,15 @@ expected labels / confidences computed once by the CPU oracle in exact mode
 
 * FAV_MATH_F32_EXACT: labels must be EXACTLY equal on all 10,000 corrupted frames (and on
   the 64-frame MC-Dropout T=30 fixture), confidences within 3e-6.
-* bf16 production mode on the same frames: it differs from the exact mode only in the MFMA
-  instruction, so labels may differ only where the oracle's own top-2 gap is small; the
-  test states the measured agreement and bounds every disagreement by that gap.
+* bf16 production mode against the f32-exact fixtures: it differs from the exact mode only in
+  the MFMA instruction, so labels may differ only where the oracle's own top-2 gap is small;
+  the test states the measured agreement and bounds every disagreement by that gap.
+* bf16 production mode against its OWN fixtures (oracle with the bit-exact model of
+  v_mfma_f32_16x16x32_bf16, `exact="mfma"`): every logit bit-identical (per-frame CRC-32 of
+  the fp32 logits), labels exactly equal, confidences within 3e-6.
 """
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -34,6 +38,41 @@ def load(name, blob_info):
     d = np.load(path)
     assert str(d["blob_sha256"]) == blob_info["sha256"], "fixture was generated with a different checkpoint"
     return d
+
+
+def frame_crc(lg):
+    lg = lg.cpu().numpy()
+    return np.array([zlib.crc32(np.ascontiguousarray(lg[:, i, :]).tobytes()) for i in range(lg.shape[1])], np.uint32)
+
+
+def test_production_mode_mc_dropout_t30_fixture(r50_blob):
+    """BASELINE configs[2] (T=30, all_blocks, p=0.1, noise severity 3) in PRODUCTION bf16 mode:
+    all 30 x 1000 logits of every frame bit-identical to the MFMA-model oracle."""
+    blob, info = r50_blob
+    d = load("r50_mfma_mc30_16.npz", info)
+    n = len(d["labels"])
+    be = Backend("resnet50", blob, max_batch=n, n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    labels, conf = be.classify(frames(0, n))
+    assert np.array_equal(frame_crc(be.logits()), d["logit_crc32"])
+    tie = d["gap"] < 1e-6
+    assert np.array_equal(labels.cpu().numpy()[~tie], d["labels"].astype(np.int32)[~tie])
+    np.testing.assert_allclose(conf.cpu().numpy(), d["conf"], rtol=0, atol=3e-6)
+    be.close()
+
+
+def test_production_mode_thousand_corrupted_frames(r50_blob):
+    """1,000 corrupted frames, single pass, PRODUCTION bf16 mode: bit-identical logits."""
+    blob, info = r50_blob
+    d = load("r50_mfma_1k_noise3.npz", info)
+    n, bs = len(d["labels"]), 250
+    be = Backend("resnet50", blob, max_batch=bs)
+    for s in range(0, n, bs):
+        labels, conf = be.classify(frames(s, bs))
+        assert np.array_equal(frame_crc(be.logits()), d["logit_crc32"][s:s + bs]), s
+        tie = d["gap"][s:s + bs] < 1e-6
+        assert np.array_equal(labels.cpu().numpy()[~tie], d["labels"][s:s + bs].astype(np.int32)[~tie])
+        np.testing.assert_allclose(conf.cpu().numpy(), d["conf"][s:s + bs], rtol=0, atol=3e-6)
+    be.close()
 
 
 def test_mc_dropout_t30_fixture(r50_blob):
