@@ -185,22 +185,23 @@ DropParams make_drop(const fav_dropout_desc* d) {
     return p;
 }
 
-// K-tile depth.  Measured on MI355X (profiles/op_table_r1.txt): the 1x1 convolutions
-// are bound by HBM and by their epilogue, and run faster with 32-deep tiles (34 KB of
-// LDS -> 4 blocks per CU hide the latency); the 3x3 convolutions are MFMA-bound and
-// run faster with 64-deep tiles (half the barriers per FLOP).  FAV_CONV_BK=32|64
-// forces one depth for experiments.
-int conv_bk(int kh, int kw) {
+// K-tile depth and ring stages of the 128-row tiles.  Measured on MI355X (profiles/r1d_conv_sweep.txt):
+//  * 3x3: MFMA-bound, 64-deep tiles (half the barriers per FLOP), double buffer;
+//  * 1x1 with a residual (the expanding convolution of a bottleneck): bound by HBM and by the
+//    epilogue; 32-deep tiles with a 3-stage ring (50 KB of LDS -> 3 blocks per CU, which is also
+//    what the 143 VGPRs allow);
+//  * 1x1 without residual: the same up to K = 256; 64-deep tiles and a double buffer from K = 512.
+// FAV_CONV_BK=32|64 and FAV_CONV_NS=2|3|4 force a value for experiments.
+int conv_bk(int kh, int kw, int K, bool has_res) {
     static int forced = [] { const char* e = getenv("FAV_CONV_BK"); return e ? atoi(e) : 0; }();
     if (forced == 32 || forced == 64) return forced;
-    return (kh * kw > 1) ? 64 : 32;
+    return (kh * kw > 1 || (!has_res && K >= 512)) ? 64 : 32;
 }
 
-// LDS stages of the K ring (2 = double buffer).  FAV_CONV_NS=2|3|4 forces.
 int conv_ns(int bk) {
     static int forced = [] { const char* e = getenv("FAV_CONV_NS"); return e ? atoi(e) : 0; }();
     if (forced >= 2 && forced <= 4) return (bk == 64 && forced == 4) ? 3 : forced;
-    return 2;
+    return bk == 32 ? 3 : 2;
 }
 
 // M-tile height: 256-row tiles (8 waves, 96 KB of LDS, one block per CU) raise the
@@ -215,15 +216,15 @@ int conv_bm(int kh, int kw, long long M) {
 
 // 256 x 256 x 64 tile (8 waves, 128 KB of LDS, one block per CU): twice the FLOPs per
 // byte staged from L2, which is what bounds the MFMA-heavy shapes.
-// Measured on MI355X it wins on the 3x3 convolutions and on the residual-free 1x1
-// convolutions with K >= 512 (+6..25 %), and loses wherever the epilogue carries a
-// residual (nothing overlaps it at one block per CU).  FAV_CONV_BIG: 0 never, 1 always
+// Measured on MI355X it wins on the residual-free 3x3 convolutions and on the 1x1
+// convolutions with K >= 512 (+6..25 %), and loses on the shallow 1x1 (K <= 256), whose
+// time is the epilogue (nothing overlaps it at one block per CU).  FAV_CONV_BIG: 0 never, 1 always
 // when Cout % 256 == 0, unset = the measured rule.
 bool conv_big(int kh, int kw, long long M, int cout_pad, int K, bool has_res) {
     static int mode = [] { const char* e = getenv("FAV_CONV_BIG"); return e ? atoi(e) : 2; }();
     if (mode == 0 || cout_pad % 256 != 0 || M < 16384) return false;
     if (mode == 1) return true;
-    return !has_res && (kh * kw > 1 || K >= 512);
+    return kh * kw > 1 ? !has_res : K >= 512;
 }
 
 const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int ldy, hipStream_t s) {
@@ -244,12 +245,13 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     p.relu = d.relu; p.out_f32 = d.out_f32;
     p.drop = make_drop(&d.drop);
     p.div_hwo = fastdiv_make((uint32_t)p.HWo);
+    p.div_w = fastdiv_make((uint32_t)p.Wo);
     if (p.drop.site >= 0 && (p.drop.v0 < 0 || p.drop.v0 + d.n_frames > 0x7fffffffLL)) return "conv: virtual frame index out of range";
     p.dbg = nullptr;
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
     const bool big = conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
-    const int BK = big ? 64 : conv_bk(d.kh, d.kw);
+    const int BK = big ? 64 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr);
     const int BM = big ? 256 : conv_bm(d.kh, d.kw, M);
     // measured: issuing the DMA after the first MFMA group gains ~7 % on the 256x256 3x3 launches and
     // loses 3-5 % on the 128-row tiles and on every 1x1
@@ -268,8 +270,66 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const double bytes = 2.0 * ((double)d.n_frames * d.H * d.W * d.Cin + (double)M * d.Cout * (d.res ? 2 : 1) * (d.out_f32 ? 2 : 1)
                                 + (double)d.Cout * p.K);
     static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
-    if (dbg_on && !h) (void)hipMalloc((void**)&p.dbg, (size_t)tiles * 32);
+    if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)tiles * 32); (void)hipMemset(p.dbg, 0, (size_t)tiles * 32); }
+    auto dbg_report = [&](long long nblocks, int bm, int bn, int bk) {
+        if (!p.dbg) return;
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> t((size_t)nblocks * 4);
+        (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(p.dbg);
+        unsigned long long lo = ~0ull, hi = 0;
+        double ph[3] = {0, 0, 0};
+        for (long long i = 0; i < nblocks; ++i) {
+            lo = std::min(lo, t[i * 4]); hi = std::max(hi, t[i * 4 + 3]);
+            for (int j = 0; j < 3; ++j) ph[j] += (double)(t[i * 4 + j + 1] - t[i * 4 + j]);
+        }
+        const double span = (double)(hi - lo), life = ph[0] + ph[1] + ph[2];
+        fprintf(stderr, "[conv dbg] blocks %lld BMxBNxBK %dx%dx%d span %.1f us; per block: prologue %.2f us, k-loop %.2f us, epilogue %.2f us; "
+                        "resident blocks/CU %.2f\n", nblocks, bm, bn, bk, span / 100.0, ph[0] / nblocks / 100.0, ph[1] / nblocks / 100.0,
+                ph[2] / nblocks / 100.0, life / span / 256.0);
+    };
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
+    // 3x3 / stride 1 / pad 1 with Cin <= 128 and the whole Cout in one tile: the input patch is staged once
+    // per 256 output pixels instead of once per tap (conv3x3_halo_kernel).  FAV_CONV_HALO=0 disables.
+    static const int halo_mode = [] { const char* e = getenv("FAV_CONV_HALO"); return e ? atoi(e) : 1; }();
+    if (halo_mode && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 && !d.res && p.drop.site < 0 && !d.out_f32 &&
+        (d.Cin == 64 || d.Cin == 128) && d.Cout == cout_pad && d.Cout == d.Cin && M >= 2048) {
+        // Cin 64: 512-pixel tiles, all 9 K tiles of the weights resident; Cin 128: 256-pixel tiles, weights double-buffered per tap
+        // 256-pixel tiles, 8 waves (measured best on both shapes); FAV_HALO_CFG=0 selects 128-pixel tiles with 4 waves and
+        // several blocks per CU for experiments
+        static const int halo_cfg = [] { const char* e = getenv("FAV_HALO_CFG"); return e ? atoi(e) : 1; }();
+        const int HBM = halo_cfg == 0 ? 128 : 256;
+        const int wstages = d.Cin == 64 ? (halo_cfg == 0 ? 2 : 3) : (halo_cfg == 0 ? 2 : 4);   // K tiles of weights held in LDS
+        const int patch_bytes = (int)((((long long)(HBM + 2 * d.W + 2) * d.Cin * 2) + 1023) / 1024 * 1024);
+        const int lds = patch_bytes + wstages * d.Cout * 128 + d.Cout * 4 + 16;
+        if (lds <= 160 * 1024) {
+            p.nk = 9 * d.Cin / 64;
+            dim3 hgrid((unsigned)((p.M + HBM - 1) / HBM));
+#define FAV_HALO(KERNEL_)                                                                                            \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            if (hipFuncSetAttribute((const void*)KERNEL_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+                return "conv: cannot reserve LDS for the staged 3x3 kernel";                                         \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(KERNEL_, hgrid, dim3(HBM * 2), lds, s, p, patch_bytes);                                   \
+    } while (0)
+            const bool bf = d.math_mode == FAV_MATH_BF16;
+            if (d.Cin == 64 && halo_cfg == 0) {
+                if (bf) FAV_HALO((conv3x3_halo_kernel<64, 64, 128, 2, 1, 3, 0>)); else FAV_HALO((conv3x3_halo_kernel<64, 64, 128, 2, 1, 3, 1>));
+            } else if (d.Cin == 64) {
+                if (bf) FAV_HALO((conv3x3_halo_kernel<64, 64, 256, 3, 1, 4, 0>)); else FAV_HALO((conv3x3_halo_kernel<64, 64, 256, 3, 1, 4, 1>));
+            } else if (halo_cfg == 0) {
+                if (bf) FAV_HALO((conv3x3_halo_kernel<128, 128, 128, 2, 1, 2, 0>)); else FAV_HALO((conv3x3_halo_kernel<128, 128, 128, 2, 1, 2, 1>));
+            } else {
+                if (bf) FAV_HALO((conv3x3_halo_kernel<128, 128, 256, 2, 2, 2, 0>)); else FAV_HALO((conv3x3_halo_kernel<128, 128, 256, 2, 2, 2, 1>));
+            }
+#undef FAV_HALO
+            dbg_report((p.M + HBM - 1) / HBM, HBM, d.Cout, 64);
+            return nullptr;
+        }
+    }
     dim3 grid((unsigned)tiles);
     p.nk = p.K / BK;
     const int NS = conv_ns(BK);
@@ -293,22 +353,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 #undef FAV_LAUNCH_MODE
 #undef FAV_LAUNCH_NS
 #undef FAV_LAUNCH
-    if (p.dbg) {
-        (void)hipStreamSynchronize(s);
-        std::vector<unsigned long long> t((size_t)tiles * 4);
-        (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(p.dbg);
-        unsigned long long lo = ~0ull, hi = 0;
-        double ph[3] = {0, 0, 0};
-        for (long long i = 0; i < tiles; ++i) {
-            lo = std::min(lo, t[i * 4]); hi = std::max(hi, t[i * 4 + 3]);
-            for (int j = 0; j < 3; ++j) ph[j] += (double)(t[i * 4 + j + 1] - t[i * 4 + j]);
-        }
-        const double span = (double)(hi - lo), life = ph[0] + ph[1] + ph[2];
-        fprintf(stderr, "[conv dbg] tiles %lld BMxBNxBK %dx%dx%d span %.1f us; per block: prologue %.2f us, k-loop %.2f us, epilogue %.2f us; "
-                        "resident blocks/CU %.2f\n", tiles, BM, BN, BK, span / 100.0, ph[0] / tiles / 100.0, ph[1] / tiles / 100.0,
-                ph[2] / tiles / 100.0, life / span / 256.0);
-    }
+    dbg_report(tiles, BM, BN, BK);
     return nullptr;
 }
 

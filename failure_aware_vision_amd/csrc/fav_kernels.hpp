@@ -190,6 +190,7 @@ struct ConvParams {
     int stage_mid;  // issue a 64-deep step's DMA after its first MFMA group (3x3) or in front (1x1)
     DropParams drop;
     FastDiv div_hwo;  // / HWo
+    FastDiv div_w;    // / Wo (the staged 3x3 kernel)
     unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
 };
 
@@ -547,6 +548,271 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
 #undef FAV_STAGE
 #undef FAV_LOAD_RES
 #undef FAV_RES_LANDED
+
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with the input staged ONCE per tile.
+//
+// The generic kernel above re-gathers the A tile for every tap: 9 x the input through
+// L2 -> LDS, and for Cin <= 128 that path (measured 15 TB/s of the ~17-19 TB/s the
+// L2 -> LDS gather sustains, profiles/r1d_pmc_3x3.txt) is what bounds the 3x3
+// convolutions of layers 1 and 2, not the MFMA.  Here a block of BM consecutive
+// output pixels m (flattened frame, y, x) stages the flattened input pixels
+// [m0 - W - 1, m0 + BM + W + 1), all Cin channels, once: tap (r, s) of output pixel m
+// is LDS row (m - m0) + r*W + s.  Where that tap falls outside the frame (which in the
+// flattened order is some neighbouring row or frame) the lane reads a 16-B zero slot
+// instead - the zero padding.  Weights are consumed in 64-channel K tiles (tap, channel
+// block) in the SAME k order as the generic kernel (k = (r*3 + s)*Cin + c ascending), so
+// the sums are bit-identical to it.  Two shapes:
+//   * Cin = Cout = 64 : BM = 512, eight waves of 64 x 64; all 9 K tiles of the weights
+//     (72 KB) are staged with the patch (79 KB for W = 56) and the K loop has no wait
+//     and no barrier at all;
+//   * Cin = Cout = 128: BM = 256, 4 x 2 waves of 64 x 64; the weights stream through a
+//     double buffer, one tap (two K tiles, 32 KB) per step and barrier.
+//
+// LDS rows are Cin*2 bytes with chunk ^= (row & 7) | ((row & 1) << 3): conflict-free
+// ds_read_b128 for any tap shift.  Epilogue: bias -> ReLU -> one bf16 rounding (these
+// convolutions carry no residual and no dropout site; the launcher sends every other
+// case to the generic kernel).
+// ---------------------------------------------------------------------------
+template <int CIN, int BN, int BM, int NS, int SUB, int OCC, int MODE>
+__global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvParams p, int patch_bytes) {
+    constexpr int NT = BM * 2, NWAVES = NT / 64;   // (BM/64) x 2 waves
+    constexpr int ROWB = CIN * 2;               // bytes per staged input pixel
+    constexpr int CPR = ROWB / 16;              // 16-B chunks per pixel (8 or 16)
+    constexpr int PROWS = 1024 / ROWB;          // pixels per 1-KiB LDS-DMA piece
+    constexpr int CB = CIN / 64;                // 64-channel K tiles per tap
+    constexpr int NKT = 9 * CB;                 // K tiles
+    constexpr int NSTEPS = NKT / SUB;           // a step = SUB K tiles = one wait + barrier
+    constexpr bool RESIDENT = NS >= NSTEPS;     // every K tile staged up front
+    constexpr int WAVES_M = BM / 64, WAVES_N = 2;
+    constexpr int WTM = 64, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int B_BYTES = BN * 128;           // one K tile of weights: BN rows x 64 k
+    constexpr int BR = B_BYTES / 1024 / NWAVES; // LDS-DMA pieces per wave per K tile
+    constexpr int OUT_LD = BN + 4;
+    static_assert(NKT % SUB == 0 && BR >= 1 && WAVES_M * WAVES_N == NWAVES, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    // [patch | NS*SUB weight K tiles | bias (BN floats) | 16 zero bytes]; the fp32 staging of the epilogue overlays the patch
+    unsigned char* const Bring = hsm + patch_bytes;
+    float* const bias_s = (float*)(Bring + NS * SUB * B_BYTES);
+    const uint32_t zero_off = (uint32_t)(patch_bytes + NS * SUB * B_BYTES + BN * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int nwg = gridDim.x;
+    int tile;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int m0 = tile * BM;
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
+    if (tid < BN) bias_s[tid] = p.bias[tid];
+    if (tid < 4) ((uint32_t*)(hsm + zero_off))[tid] = 0u;
+
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)hsm);
+    // ---- stage the patch ------------------------------------------------------
+    const int W = p.W;
+    const long long g0 = (long long)m0 - W - 1;              // global pixel of patch row 0
+    const long long gbase = g0 > 0 ? g0 : 0;
+    const __amdgpu_buffer_rsrc_t srd_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + gbase * CIN), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+    {
+        const int npieces = patch_bytes >> 10;
+        const int lrow = lane / CPR, lslot = lane % CPR;
+        for (int j = wave_u; j < npieces; j += NWAVES) {
+            const int q = j * PROWS + lrow;                  // patch row of this lane
+            const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
+            const long long g = g0 + q;
+            const bool ok = g >= 0 && g < (long long)p.M;
+            const uint32_t voff = ok ? (uint32_t)((g - gbase) * ROWB + ((lslot ^ sw) << 4)) : OOB;
+            lds_dma16(srd_a, voff, 0u, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)j * 1024u));
+        }
+    }
+    // ---- weights -------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t srd_b =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, BN * p.K * 2, 0x00020000);
+    uint32_t b_voff[BR];
+    {
+        const int lrow = lane >> 3, lch = (lane & 7) ^ (lrow & 7);
+#pragma unroll
+        for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)((((wave * BR + i) * 8 + lrow) * p.K + lch * 8) * 2);
+    }
+    const uint32_t lds_b = lds_base + (uint32_t)patch_bytes + wave_u * (BR * 1024);
+// K tiles [STEP*SUB, STEP*SUB + SUB) into ring slot BUF
+#define FAV_HSTAGE(BUF, STEP)                                                                          \
+    do {                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < SUB; ++u)                                                \
+            _Pragma("unroll") for (int i = 0; i < BR; ++i)                                             \
+                lds_dma16(srd_b, b_voff[i], (uint32_t)(((STEP) * SUB + u) * 128),                      \
+                          __builtin_amdgcn_readfirstlane(lds_b + ((BUF) * SUB + u) * B_BYTES + i * 1024)); \
+    } while (0)
+    constexpr int PIECES = BR * SUB;
+    if (RESIDENT) {
+#pragma unroll
+        for (int t = 0; t < NSTEPS; ++t) FAV_HSTAGE(t, t);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t) FAV_HSTAGE(t, t);
+    }
+
+    // ---- per-lane row geometry ---------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;
+    uint32_t tapmask[TM];                                    // bit (r*3+s): the tap lies inside the frame
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * WTM + b * 16 + frow;
+        uint32_t mk = 0;
+        if (m < p.M) {
+            const uint32_t vl = fastdiv((uint32_t)m, p.div_hwo);
+            const uint32_t pix = (uint32_t)m - vl * (uint32_t)p.HWo;
+            const uint32_t y = fastdiv(pix, p.div_w), x = pix - y * (uint32_t)W;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if ((unsigned)((int)y + r - 1) < (unsigned)p.H && (unsigned)((int)x + s - 1) < (unsigned)W) mk |= 1u << (r * 3 + s);
+        }
+        tapmask[b] = mk;
+    }
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // the patch and the first weight step (RESIDENT: everything) have landed
+    if (RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
+    __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 1] = wall_clock64();
+
+    int cur = 0, nxt = NS - 1;
+    int tap = 0, cb = 0, tapoff = 0, tr = 0, ts = 0;        // tapoff = r*W + s
+    for (int step = 0; step < NSTEPS; ++step) {
+        if (!RESIDENT && step + NS - 1 < NSTEPS) FAV_HSTAGE(nxt, step + NS - 1);
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            const unsigned char* Bs = Bring + (cur * SUB + u) * B_BYTES;
+            uint32_t a_addr[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int q = wm * WTM + b * 16 + frow + tapoff;
+                const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
+                const uint32_t ad = (uint32_t)q * ROWB + (uint32_t)(((cb * 8 + fq) ^ sw) << 4);
+                a_addr[b] = ((tapmask[b] >> tap) & 1u) ? ad : zero_off;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 fx[TM], fw[TN];
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    // chunk + 4 flips bit 2 of the (swizzled) chunk index: address ^ 64; the zero slot is read as is
+                    const uint32_t ad = (a_addr[b] == zero_off) ? zero_off : (a_addr[b] ^ (uint32_t)(kk << 6));
+                    fx[b] = *(const uint4*)(hsm + ad);
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int row = wn * WTN + a * 16 + frow;
+                    fw[a] = *(const uint4*)(Bs + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+                }
+                if (MODE == 0) {
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+#pragma unroll
+                        for (int b = 0; b < TM; ++b) {
+                            union { uint4 u; bf16x8_t v; } ua, ub;
+                            ua.u = fw[a];
+                            ub.u = fx[b];
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[a][b], 0, 0, 0);
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int a = 0; a < TN; ++a) {
+                            const uint32_t wa = ((const uint32_t*)&fw[a])[j >> 1];
+                            const float wf = bf16_bits_to_f32((j & 1) ? (wa >> 16) : (wa & 0xFFFFu));
+#pragma unroll
+                            for (int b = 0; b < TM; ++b) {
+                                const uint32_t xa = ((const uint32_t*)&fx[b])[j >> 1];
+                                const float xf = bf16_bits_to_f32((j & 1) ? (xa >> 16) : (xa & 0xFFFFu));
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf, acc[a][b], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            if (++cb == CB) {
+                cb = 0;
+                ++tap;
+                if (++ts == 3) { ts = 0; ++tr; }
+                tapoff = tr * W + ts;
+            }
+        }
+        if (RESIDENT) {
+            ++cur;
+        } else {
+            if (step + NS - 1 < NSTEPS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+    }
+#undef FAV_HSTAGE
+    if (RESIDENT) __syncthreads();   // every wave is done with the patch before the staging overwrites it
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 2] = wall_clock64();
+
+    // ---- epilogue: GROWS rows at a time through LDS (over the patch), 16 channels per thread ----
+    constexpr int NCH = BN / 16;
+    constexpr int GROWS = (NT / NCH >= 128 && BM >= 128) ? 128 : 64;   // rows staged per round: every thread busy when it can be
+    constexpr int RPP = (NT / NCH > GROWS) ? GROWS : NT / NCH;
+    constexpr int NPASS = GROWS / RPP;
+    constexpr int WPG = GROWS / 64;                                     // wave rows per round
+    const int ec = tid % NCH, er = tid / NCH;
+    const int n = ec * 16;
+    float* outs = (float*)hsm;
+#pragma unroll 1
+    for (int grp = 0; grp < BM / GROWS; ++grp) {
+        if (grp > 0) __syncthreads();
+        if (wm / WPG == grp) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    *(f32x4_t*)(outs + ((wm % WPG) * 64 + b * 16 + frow) * OUT_LD + wn * WTN + a * 16 + fq * 4) = acc[a][b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int ml = er + pass * RPP;
+            const int m = m0 + grp * GROWS + ml;
+            if (er >= GROWS || m >= p.M) continue;
+            uint32_t o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t4 = *(const float4*)(outs + ml * OUT_LD + n + 4 * q);
+                const float4 bq = *(const float4*)(bias_s + n + 4 * q);
+                float v0 = __fadd_rn(t4.x, bq.x), v1 = __fadd_rn(t4.y, bq.y), v2 = __fadd_rn(t4.z, bq.z), v3 = __fadd_rn(t4.w, bq.w);
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                o[2 * q] = pack_bf16x2(v0, v1);
+                o[2 * q + 1] = pack_bf16x2(v2, v3);
+            }
+            uint4* yo = (uint4*)((uint16_t*)p.y + (long long)m * p.ldy + n);
+            yo[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            yo[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+    }
+    if (p.dbg) {
+        __syncthreads();
+        if (tid == 0) p.dbg[blockIdx.x * 4ull + 3] = wall_clock64();
+    }
+}
 
 // ---------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max pool, NHWC bf16; one thread = 8 channels of one output

@@ -42,6 +42,29 @@ def test_conv_exact_bitwise(lib, cin, cout, k, stride, pad, H, W, n):
     assert np.array_equal(got2, O.epilogue(acc, b, res=res, relu=True))
 
 
+@pytest.mark.parametrize("c,H,W,n", [
+    (64, 56, 56, 2),     # M = 6272: 24.5 tiles of 256 pixels (ragged last tile)
+    (64, 60, 80, 1),     # H != W (the 240x320 seam at layer 1)
+    (64, 7, 9, 37),      # frames much smaller than a tile: every tile spans many frames
+    (128, 28, 28, 5),    # 256-B LDS rows
+    (128, 14, 14, 13),
+])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv3x3_staged_patch_bitwise(lib, c, H, W, n, mode):
+    """The 3x3 kernel that stages the input patch once per 256 output pixels (conv3x3_halo_kernel):
+    bit-identical to the oracle in BOTH math modes (bf16-MFMA model / f32 chain), including the
+    frame borders, where a tap's LDS row belongs to a neighbouring image row or frame."""
+    rng = np.random.default_rng(c + H * W + n)
+    x = O.bf16_round((rng.standard_normal((n, H, W, c)) * np.exp2(rng.integers(-2, 3, (n, H, W, c)))).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((c, 3, 3, c)) * np.sqrt(2.0 / (9 * c))).astype(np.float32))
+    b = (rng.standard_normal(c) * 0.2).astype(np.float32)
+    acc = O.conv_acc_exact(x, w, 3, 3, 1, 1, mode="mfma" if mode == 0 else "f32")
+    for relu in (1, 0):
+        got = run_conv(lib, x, w, b, None, 1, 1, relu=relu, math_mode=mode)
+        exp = O.epilogue(acc, b, res=None, relu=bool(relu))
+        assert np.array_equal(got, exp), f"{np.mean(got != exp):.5f} of elements differ"
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,n,use_res", [
     (64, 64, 1, 1, 0, 14, 14, 3, False), (64, 128, 3, 2, 1, 15, 15, 2, True), (128, 256, 3, 1, 1, 9, 9, 2, False),
     (512, 128, 1, 1, 0, 7, 7, 3, True), (192, 64, 1, 1, 0, 16, 16, 2, False),

@@ -16,6 +16,10 @@ SHAPES = [  # name, H, Cin, Cout, k, stride, res, drop
     ("L3c3 1x1 256->1024 +res+drop", 14, 256, 1024, 1, 1, 1, 1),
     ("L4c1 1x1 2048->512", 7, 2048, 512, 1, 1, 0, 0), ("L4c2 3x3 512->512", 7, 512, 512, 3, 1, 0, 0),
     ("L4c3 1x1 512->2048 +res+drop", 7, 512, 2048, 1, 1, 1, 1),
+    ("T2c1 1x1 256->128 @56", 56, 256, 128, 1, 1, 0, 0), ("T2ds 1x1s2 256->512 @56", 56, 256, 512, 1, 2, 0, 0),
+    ("T2c2 3x3s2 128->128 @56", 56, 128, 128, 3, 2, 0, 0),
+    ("T3c1 1x1 512->256 @28", 28, 512, 256, 1, 1, 0, 0), ("T3ds 1x1s2 512->1024 @28", 28, 512, 1024, 1, 2, 0, 0),
+    ("T3c2 3x3s2 256->256 @28", 28, 256, 256, 3, 2, 0, 0),
     ("X L3c3 plain", 14, 256, 1024, 1, 1, 0, 0), ("X L3c3 +res", 14, 256, 1024, 1, 1, 1, 0), ("X L3c3 +drop", 14, 256, 1024, 1, 1, 0, 1),
     ("X L1c3 plain", 56, 64, 256, 1, 1, 0, 0), ("X L1c3 +res", 56, 64, 256, 1, 1, 1, 0), ("X L1c3 +drop", 56, 64, 256, 1, 1, 0, 1),
 ]
