@@ -216,14 +216,14 @@ constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
     return blocks * (BM * 2 / 64) / 4;
 }
 
-template <int BM, int BN, int BK, int NS, int MODE>
-__global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p) {
-    constexpr int NT = BM * 2;                  // threads: (BM/64) x 2 waves, each a 64 x BN/2 sub-tile
+template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0>
+__global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int NT = (BM / 64) * WN * 64;     // threads: (BM/64) x WN waves, each a 64 x BN/WN sub-tile
     constexpr int NWAVES = NT / 64;
     constexpr int ROWB = BK * 2;                // bytes per staged row
     constexpr int CPR = BK / 8;                 // 16-B chunks per row
     constexpr int PROWS = 1024 / ROWB;          // rows per 1-KiB LDS-DMA piece
-    constexpr int WTM = 64, WTN = BN / 2;       // wave tile
+    constexpr int WTM = 64, WTN = BN / WN;      // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16; // 16x16 MFMA tiles per wave
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BM * 2, conv_waves_per_simd(BM, BN, BK, NS)) void c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
 
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (L2); give each XCD a
