@@ -36,7 +36,7 @@ def conv_sum(sub, counter):
     tot, n = 0.0, 0
     if f:
         for row in csv.DictReader(open(f)):
-            if "conv_igemm_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            if ("conv_igemm_kernel" in row["Kernel_Name"] or "conv3x3_halo_kernel" in row["Kernel_Name"]) and row["Counter_Name"] == counter:
                 tot += float(row["Counter_Value"]); n += 1
     return tot, n
 fs, fn = conv_sum("pmc_fetch", "FETCH_SIZE")
