@@ -18,7 +18,7 @@ FAV_OK = 0
 STATUS_NAMES = {0: "FAV_OK", 1: "FAV_ERR_INVALID_ARG", 2: "FAV_ERR_BAD_BLOB", 3: "FAV_ERR_NO_WEIGHTS",
                 4: "FAV_ERR_HIP", 5: "FAV_ERR_NO_DEVICE", 6: "FAV_ERR_UNSUPPORTED"}
 LAYOUT_NHWC_U8, LAYOUT_NHWC_F32 = 0, 1
-ARCH_RESNET18_CIFAR, ARCH_RESNET50 = 0, 1
+ARCH_RESNET18_CIFAR, ARCH_RESNET50, ARCH_VIT_B16, ARCH_VIT_TINY = 0, 1, 2, 3
 CONF_MAX_SOFTMAX, CONF_ENTROPY = 0, 1
 MATH_BF16, MATH_F32_EXACT = 0, 1
 K_STEM, K_CONV, K_MAXPOOL, K_AVGPOOL, K_DROPOUT, K_HEAD, K_COUNT = 0, 1, 2, 3, 4, 5, 6
@@ -86,6 +86,10 @@ _SIGNATURES = {
                                  C.c_void_p]),
     "fav_op_entry_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(FavDropoutDesc),
                                        C.c_void_p]),
+    "fav_op_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                   C.c_void_p]),
+    "fav_op_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "fav_op_vit_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "fav_op_head": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

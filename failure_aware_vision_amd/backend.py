@@ -23,7 +23,8 @@ import numpy as np
 
 from . import _lib, weights as _weights
 
-_ARCH = {"resnet18_cifar": _lib.ARCH_RESNET18_CIFAR, "resnet50": _lib.ARCH_RESNET50}
+_ARCH = {"resnet18_cifar": _lib.ARCH_RESNET18_CIFAR, "resnet50": _lib.ARCH_RESNET50, "vit_b16": _lib.ARCH_VIT_B16,
+         "vit_tiny": _lib.ARCH_VIT_TINY}
 _CONF = {"max_softmax": _lib.CONF_MAX_SOFTMAX, "entropy": _lib.CONF_ENTROPY}
 _MATH = {"bf16": _lib.MATH_BF16, "f32_exact": _lib.MATH_F32_EXACT}
 
@@ -75,7 +76,10 @@ class Backend:
             for i, b in enumerate(members):
                 self.load_weights(b, member=i)
         else:
-            if blob is None:
+            if blob is None and _ARCH[arch] in _weights.VIT_CFG:
+                blob, self.weights_info = _weights.make_synthetic_vit(arch, seed=seed_weights, num_classes=cfg.num_classes,
+                                                                     in_hw=(cfg.in_h, cfg.in_w))
+            elif blob is None:
                 blob, self.weights_info = _weights.make_synthetic(arch, seed=seed_weights, num_classes=cfg.num_classes)
             self.load_weights(blob)
         self.mc = cfg.site_mask != 0 and round(cfg.dropout_p * 256) > 0

@@ -55,6 +55,11 @@ const ArchDef kArch[2] = {
     {true, {3, 4, 6, 3}, {64, 128, 256, 512}, true},
 };
 
+struct VitDef { int dim, depth, heads, mlp, patch; };
+// arch 2 = ViT-B/16 (BASELINE configs[4]); arch 3 = a two-layer miniature of it for the parity tests
+const VitDef kVit[2] = {{768, 12, 12, 3072, 16}, {128, 2, 2, 256, 16}};
+inline bool is_vit_arch(int arch) { return arch == 2 || arch == 3; }
+
 struct Layer {  // one convolution / fc
     int cout, cin, kh, kw, stride, pad;
     int cout_pad, k;         // device layout: w[cout_pad][k], bias[cout_pad]
@@ -120,6 +125,10 @@ struct fav_handle {
     int T_eff = 1;                  // samples actually run
     int first_site = -1;
     void* host_stage = nullptr;     // for fav_classify_host
+    // ViT path (arch 2, 3): layers in blob order (kh == 0: a pair of fp32 vectors kept in w / b), fixed buffers
+    bool vit = false;
+    int vit_ntok = 0;
+    void *v_patches = nullptr, *v_emb = nullptr, *v_x = nullptr, *v_y = nullptr, *v_qkv = nullptr, *v_hid = nullptr, *v_cls = nullptr;
     // profiling
     bool profiling = false;
     struct Ev { hipEvent_t a, b; int cls; int op; };
@@ -418,6 +427,42 @@ const char* launch_head(fav_handle* h, const float* logits, int T, int n, int C,
 }
 
 // ------------------------------------------------------------------ graph build
+// ------------------------------------------------------------------ ViT launchers
+const char* launch_layernorm(fav_handle* h, const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long rows,
+                             int D, float eps, hipStream_t s) {
+    if (D % 4 != 0 || D > 1024 || rows < 1) return "layernorm: need D % 4 == 0, D <= 1024";
+    Prof pr(h, s, FAV_K_AVGPOOL, 0.0, (double)rows * D * 4);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const uint16_t*)x, ldx, gamma, beta,
+                       (uint16_t*)y, rows, D, eps);
+    return nullptr;
+}
+
+const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, int T, int D, int heads, int math_mode, hipStream_t s) {
+    if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
+    const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
+    const int lds = nkt * 16 * 128 + 64 * vstride + 4 * 16 * vstride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return "attention: cannot reserve LDS";
+        attr_set = true;
+    }
+    const double flops = 4.0 * n * heads * (double)T * T * 64;
+    Prof pr(h, s, FAV_K_CONV, flops, (double)n * T * D * 2 * 4);
+    if (math_mode == FAV_MATH_BF16)
+        hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)(n * heads)), dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+    else
+        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)(n * heads)), dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+    return nullptr;
+}
+
+void launch_vit_assemble(fav_handle* h, const void* emb, const float* pos, void* x, int n, int ntok, int D, hipStream_t s) {
+    const long long total = (long long)n * ntok * (D / 4);
+    Prof pr(h, s, FAV_K_STEM, 0.0, (double)n * ntok * D * 4);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)emb, pos, (uint16_t*)x, n, ntok, D);
+}
+
 fav_status build_graph(fav_handle* h) {
     const fav_config& c = h->cfg;
     const ArchDef& A = kArch[c.arch];
@@ -797,7 +842,96 @@ void free_all(fav_handle* h) {
     for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
     if (h->logits) (void)hipFree(h->logits);
     if (h->host_stage) (void)hipFree(h->host_stage);
+    for (void* q : {h->v_patches, h->v_emb, h->v_x, h->v_y, h->v_qkv, h->v_hid, h->v_cls}) if (q) (void)hipFree(q);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+}
+
+
+// ViT: layers in blob order, fixed buffers, no phases (single deterministic pass).
+fav_status build_vit(fav_handle* h) {
+    const fav_config& c = h->cfg;
+    const VitDef& V = kVit[c.arch - 2];
+    if (c.in_h % V.patch || c.in_w % V.patch) { h->err = "ViT input must be a multiple of the patch size"; return FAV_ERR_INVALID_ARG; }
+    const int np = (c.in_h / V.patch) * (c.in_w / V.patch), ntok = np + 1;
+    if (ntok > 256) { h->err = "ViT path supports at most 256 tokens"; return FAV_ERR_UNSUPPORTED; }
+    if (c.site_mask != 0 && c.dropout_p > 0.f) { h->err = "the ViT path has no dropout sites"; return FAV_ERR_UNSUPPORTED; }
+    if (c.n_members > 1) { h->err = "the ViT path has no ensemble mode"; return FAV_ERR_UNSUPPORTED; }
+    h->vit = true;
+    h->vit_ntok = ntok;
+    h->T_eff = 1;
+    h->layers.clear();
+    auto lin = [&](int cout, int cin, int kh, int kw, int stride) {
+        Layer L; L.cout = cout; L.cin = cin; L.kh = kh; L.kw = kw; L.stride = stride; L.pad = 0;
+        L.cout_pad = (cout + 63) / 64 * 64; L.k = kh * kw * cin;
+        h->layers.push_back(L);
+    };
+    auto vec = [&](int len) {
+        Layer L; L.cout = len; L.cin = 0; L.kh = 0; L.kw = 0; L.stride = 0; L.pad = 0; L.cout_pad = len; L.k = 0;
+        h->layers.push_back(L);
+    };
+    lin(V.dim, 3, V.patch, V.patch, V.patch);
+    vec(ntok * V.dim);
+    for (int i = 0; i < V.depth; ++i) {
+        vec(V.dim); lin(3 * V.dim, V.dim, 1, 1, 1); lin(V.dim, V.dim, 1, 1, 1);
+        vec(V.dim); lin(V.mlp, V.dim, 1, 1, 1); lin(V.dim, V.mlp, 1, 1, 1);
+    }
+    vec(V.dim);
+    lin(c.num_classes, V.dim, 1, 1, 1);
+    h->cpad = h->layers.back().cout_pad;
+    HIP_TRY(h, hipSetDevice(c.device));
+    const size_t B = (size_t)c.max_batch, D = (size_t)V.dim;
+    HIP_TRY(h, hipMalloc(&h->v_patches, B * np * (size_t)(V.patch * V.patch * 3) * 2 + 256));
+    HIP_TRY(h, hipMalloc(&h->v_emb, B * np * D * 2 + 256));
+    HIP_TRY(h, hipMalloc(&h->v_x, B * ntok * D * 2 + 256));
+    HIP_TRY(h, hipMalloc(&h->v_y, B * ntok * D * 2 + 256));
+    HIP_TRY(h, hipMalloc(&h->v_qkv, B * ntok * 3 * D * 2 + 256));
+    HIP_TRY(h, hipMalloc(&h->v_hid, B * ntok * (size_t)V.mlp * 2 + 256));
+    HIP_TRY(h, hipMalloc(&h->v_cls, B * D * 2 + 256));
+    HIP_TRY(h, hipMalloc((void**)&h->logits, B * h->cpad * 4 + 256));
+    return FAV_OK;
+}
+
+// One forward pass of the ViT encoder over n frames -> fp32 logits [n][cpad].
+fav_status run_vit(fav_handle* h, const void* images, int layout, int n, hipStream_t s) {
+    const fav_config& c = h->cfg;
+    const VitDef& V = kVit[c.arch - 2];
+    const int ntok = h->vit_ntok, D = V.dim, gh = c.in_h / V.patch, gw = c.in_w / V.patch;
+    const float inv_std[3] = {1.0f / c.stdev[0], 1.0f / c.stdev[1], 1.0f / c.stdev[2]};
+    auto gemm = [&](int layer, const void* x, int rows_per_frame, const void* res, int act, void* y, int out_f32) -> const char* {
+        const Layer& L = h->layers[layer];
+        fav_conv_desc d;
+        memset(&d, 0, sizeof d);
+        d.x = x; d.w = L.w; d.bias = L.b; d.res = res; d.y = y;
+        d.n_frames = n; d.H = rows_per_frame; d.W = 1; d.Cin = L.k; d.Cout = L.cout;
+        d.kh = 1; d.kw = 1; d.stride = 1; d.pad = 0; d.relu = act; d.out_f32 = out_f32; d.math_mode = c.math_mode;
+        d.drop.site = -1;
+        return launch_conv(h, d, L.cout_pad, out_f32 ? L.cout_pad : L.cout, s);
+    };
+#define FAV_VIT_TRY(expr)                                            \
+    do {                                                             \
+        if (const char* e_ = (expr)) { h->err = e_; return FAV_ERR_INVALID_ARG; } \
+    } while (0)
+    h->cur_op = -1;
+    // patch embedding: normalise + im2col (k = (r*P + s)*3 + c), GEMM, add positions / class token
+    launch_stem(h, images, layout, n, c.in_h, c.in_w, V.patch, V.patch, V.patch, 0, V.patch * V.patch * 3, c.mean, inv_std, h->v_patches, s);
+    FAV_VIT_TRY(gemm(0, h->v_patches, gh * gw, nullptr, 0, h->v_emb, 0));
+    launch_vit_assemble(h, h->v_emb, (const float*)h->layers[1].w, h->v_x, n, ntok, D, s);
+    int li = 2;
+    for (int blk = 0; blk < V.depth; ++blk, li += 6) {
+        const Layer &ln1 = h->layers[li], &ln2 = h->layers[li + 3];
+        FAV_VIT_TRY(launch_layernorm(h, h->v_x, D, (const float*)ln1.w, ln1.b, h->v_y, (long long)n * ntok, D, 1e-6f, s));
+        FAV_VIT_TRY(gemm(li + 1, h->v_y, ntok, nullptr, 0, h->v_qkv, 0));
+        FAV_VIT_TRY(launch_attention(h, h->v_qkv, h->v_y, n, ntok, D, V.heads, c.math_mode, s));
+        FAV_VIT_TRY(gemm(li + 2, h->v_y, ntok, h->v_x, 0, h->v_x, 0));                 // x = x + proj(attn), in place tile by tile
+        FAV_VIT_TRY(launch_layernorm(h, h->v_x, D, (const float*)ln2.w, ln2.b, h->v_y, (long long)n * ntok, D, 1e-6f, s));
+        FAV_VIT_TRY(gemm(li + 4, h->v_y, ntok, nullptr, 2, h->v_hid, 0));              // GELU fused
+        FAV_VIT_TRY(gemm(li + 5, h->v_hid, ntok, h->v_x, 0, h->v_x, 0));
+    }
+    const Layer& lnf = h->layers[li];
+    FAV_VIT_TRY(launch_layernorm(h, h->v_x, (long long)ntok * D, (const float*)lnf.w, lnf.b, h->v_cls, n, D, 1e-6f, s));   // class tokens only
+    FAV_VIT_TRY(gemm(li + 1, h->v_cls, 1, nullptr, 0, h->logits, 1));
+#undef FAV_VIT_TRY
+    return FAV_OK;
 }
 
 }  // namespace
@@ -815,8 +949,8 @@ void fav_default_config(fav_config* c, int32_t arch) {
     c->struct_size = sizeof *c;
     c->device = 0;
     c->arch = arch;
-    c->num_classes = arch == FAV_ARCH_RESNET50 ? 1000 : 10;
-    c->in_h = c->in_w = arch == FAV_ARCH_RESNET50 ? 224 : 32;
+    c->num_classes = arch == FAV_ARCH_RESNET18_CIFAR ? 10 : 1000;
+    c->in_h = c->in_w = (arch == FAV_ARCH_RESNET50 || arch == FAV_ARCH_VIT_B16) ? 224 : (arch == FAV_ARCH_VIT_TINY ? 64 : 32);
     c->max_batch = 256;
     c->mean[0] = 0.485f; c->mean[1] = 0.456f; c->mean[2] = 0.406f;
     c->stdev[0] = 0.229f; c->stdev[1] = 0.224f; c->stdev[2] = 0.225f;
@@ -838,7 +972,7 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out) {
     if (out) *out = nullptr;
     if (!cfg || !out) { g_create_error = "fav_create: null argument"; return FAV_ERR_INVALID_ARG; }
     if (cfg->struct_size != sizeof(fav_config)) { g_create_error = "fav_create: fav_config.struct_size mismatch"; return FAV_ERR_INVALID_ARG; }
-    if (cfg->arch < 0 || cfg->arch > 1) { g_create_error = "fav_create: unknown arch"; return FAV_ERR_UNSUPPORTED; }
+    if (cfg->arch < 0 || cfg->arch > 3) { g_create_error = "fav_create: unknown arch"; return FAV_ERR_UNSUPPORTED; }
     if (cfg->num_classes < 1 || cfg->num_classes > 1024 || cfg->max_batch < 1 || cfg->in_h < 8 || cfg->in_w < 8 ||
         cfg->n_samples < 1 || cfg->n_samples > 4096 || !(cfg->temperature > 0.f) || cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f ||
         !(cfg->stdev[0] > 0.f && cfg->stdev[1] > 0.f && cfg->stdev[2] > 0.f) || cfg->math_mode < 0 || cfg->math_mode > 1 ||
@@ -863,8 +997,8 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out) {
     h->n_members = cfg->n_members > 1 ? cfg->n_members : 1;
     h->member_loaded.assign(h->n_members, 0);
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; delete h; return FAV_ERR_HIP; }
-    fav_status st = build_graph(h);
-    if (st == FAV_OK) st = plan_memory(h);
+    fav_status st = is_vit_arch(cfg->arch) ? build_vit(h) : build_graph(h);
+    if (st == FAV_OK && !h->vit) st = plan_memory(h);
     if (st != FAV_OK) { g_create_error = h->err; free_all(h); delete h; return st; }
     *out = h;
     return FAV_OK;
@@ -908,6 +1042,17 @@ fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* bl
             h->err = fmt("fav_load_weights: layer %zu shape mismatch", i);
             return FAV_ERR_BAD_BLOB;
         }
+        if (L.kh == 0) {   // a pair of fp32 vectors (LayerNorm gamma / beta, ViT position table)
+            const size_t vb = (size_t)L.cout * 4;
+            if (off[0] + vb > size || off[1] + vb > size) { h->err = fmt("fav_load_weights: layer %zu data out of range", i); return FAV_ERR_BAD_BLOB; }
+            L.w_m.resize(h->n_members, nullptr);
+            L.b_m.resize(h->n_members, nullptr);
+            if (!L.w_m[member]) HIP_TRY(h, hipMalloc((void**)&L.w_m[member], vb));
+            if (!L.b_m[member]) HIP_TRY(h, hipMalloc((void**)&L.b_m[member], vb));
+            HIP_TRY(h, hipMemcpy(L.w_m[member], p + off[0], vb, hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMemcpy(L.b_m[member], p + off[1], vb, hipMemcpyHostToDevice));
+            continue;
+        }
         const size_t kreal = (size_t)L.kh * L.kw * L.cin;
         const size_t wbytes = (size_t)L.cout * kreal * 2, bbytes = (size_t)L.cout * 4;
         if (off[0] + wbytes > size || off[1] + bbytes > size) { h->err = fmt("fav_load_weights: layer %zu data out of range", i); return FAV_ERR_BAD_BLOB; }
@@ -941,6 +1086,11 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     h->ev_used = h->profiling ? h->ev_used : 0;
+    if (h->vit) {
+        for (auto& L : h->layers) { L.w = L.w_m[0]; L.b = L.b_m[0]; }
+        fav_status st = run_vit(h, images, layout, n, s);
+        if (st != FAV_OK) return st;
+    } else
     for (int member = 0; member < h->n_members; ++member) {
     for (auto& L : h->layers) { L.w = L.w_m[member]; L.b = L.b_m[member]; }
     // member m writes logits[m][n][cpad]: the head then averages members exactly as it averages samples
@@ -980,7 +1130,7 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_b, 0));
     }
     }
-    h->phase_out.back() = h->logits;
+    if (!h->vit) h->phase_out.back() = h->logits;
     const int T_head = h->n_members > 1 ? h->n_members : h->T_eff;
     if (const char* e = launch_head(h, h->logits, T_head, n, h->cfg.num_classes, h->cpad, h->cfg.temperature,
                                     h->cfg.conf_kind, h->cfg.tau, labels, conf, fail, score, s)) {
@@ -1120,6 +1270,24 @@ fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t C, int
                        float tau, int32_t* labels, float* conf, uint8_t* fail, float* score, void* stream) {
     if (!logits || !labels || !conf || T < 1 || n < 1 || !(temperature > 0.f)) return op_done("fav_op_head: bad argument");
     return op_done(launch_head(nullptr, logits, T, n, C, ld, temperature, kind, tau, labels, conf, fail, score, (hipStream_t)stream));
+}
+
+fav_status fav_op_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t rows, int32_t D,
+                            float eps, void* stream) {
+    if (!x || !gamma || !beta || !y) return op_done("fav_op_layernorm: null pointer");
+    return op_done(launch_layernorm(nullptr, x, ldx, gamma, beta, y, rows, D, eps, (hipStream_t)stream));
+}
+
+fav_status fav_op_attention(const void* qkv, void* out, int32_t n, int32_t T, int32_t D, int32_t heads, int32_t math_mode,
+                            void* stream) {
+    if (!qkv || !out) return op_done("fav_op_attention: null pointer");
+    return op_done(launch_attention(nullptr, qkv, out, n, T, D, heads, math_mode, (hipStream_t)stream));
+}
+
+fav_status fav_op_vit_assemble(const void* emb, const float* pos, void* x, int32_t n, int32_t ntok, int32_t D, void* stream) {
+    if (!emb || !pos || !x || n < 1 || ntok < 2 || D % 4 != 0) return op_done("fav_op_vit_assemble: bad argument");
+    launch_vit_assemble(nullptr, emb, pos, x, n, ntok, D, (hipStream_t)stream);
+    return op_done(nullptr);
 }
 
 fav_status fav_op_signal_stats(const uint8_t* frames, int32_t n, int32_t H, int32_t W, const uint8_t* prev_gray,

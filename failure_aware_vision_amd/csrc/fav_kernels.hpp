@@ -35,6 +35,39 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// ---------------------------------------------------------------------------
+// exp and tanh-form GELU as fixed sequences of IEEE fp32 operations (the ViT path).  The CPU
+// oracle (oracle/fav_exact.c: fav_expf_ref, fav_gelu_ref) executes the same sequence, so the
+// results are bit-identical; libm's expf / tanhf would differ by an ulp here and there.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fav_expf(float x) {
+    if (!(x >= -80.0f)) return 0.0f;   // also NaN -> 0; keeps every result a normal number
+    if (x > 88.0f) x = 88.0f;
+    const float k = rintf(__fmul_rn(x, 0x1.715476p+0f));
+    float r = __fmaf_rn(-k, 0x1.62e400p-1f, x);
+    r = __fmaf_rn(-k, 0x1.7f7d1cp-20f, r);
+    float p = 0x1.6c16c2p-10f;
+    p = __fmaf_rn(p, r, 0x1.111112p-7f);
+    p = __fmaf_rn(p, r, 0x1.555556p-5f);
+    p = __fmaf_rn(p, r, 0x1.555556p-3f);
+    p = __fmaf_rn(p, r, 0.5f);
+    p = __fmaf_rn(p, r, 1.0f);
+    p = __fmaf_rn(p, r, 1.0f);
+    return ldexpf(p, (int)k);
+}
+// Correctly rounded fp32 square root: __fsqrt_rn maps to the 1-ulp hardware approximation on this target
+// (measured: 11 % of random inputs differ from IEEE), so go through the correctly rounded f64 root - rounding
+// that to fp32 is exact-rounded as well (53 >= 2*24 + 2 bits).
+__device__ __forceinline__ float fav_sqrtf(float x) { return (float)sqrt((double)x); }
+__device__ __forceinline__ float fav_gelu(float x) {
+    const float x3 = __fmul_rn(__fmul_rn(x, x), x);
+    const float inner = __fadd_rn(x, __fmul_rn(0x1.6e4e26p-5f, x3));
+    const float z = __fmul_rn(0x1.988454p-1f, inner);
+    const float e = fav_expf(__fadd_rn(z, z));
+    const float t = __fsub_rn(1.0f, __fdiv_rn(2.0f, __fadd_rn(e, 1.0f)));
+    return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, t));
+}
+
 // Philox4x32-10 (Random123).  counter = (chunk, frame, sample, site), key = seed.
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -185,7 +218,7 @@ struct ConvParams {
     int kw, stride, pad;
     int M;          // n_frames * Ho * Wo
     int K, nk;      // K = kh*kw*Cin, nk = K / BK
-    int relu, out_f32;
+    int relu, out_f32;   // relu: 0 none, 1 ReLU, 2 tanh-form GELU
     int tiles_m, tiles_n;
     int stage_mid;  // issue a 64-deep step's DMA after its first MFMA group (3x3) or in front (1x1)
     DropParams drop;
@@ -516,9 +549,12 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                         v[2 * j + 1] = __fadd_rn(v[2 * j + 1], bf16_bits_to_f32(rw[j] >> 16));
                     }
                 }
-                if (p.relu) {
+                if (p.relu == 1) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                } else if (p.relu == 2) {   // tanh-form GELU (ViT MLP)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fav_gelu(v[j]);
                 }
                 if (p.out_f32) {
                     float* yo = (float*)p.y + (long long)m * p.ldy + n + 8 * g;
@@ -924,6 +960,231 @@ __global__ __launch_bounds__(256) void entry_dropout_kernel(const uint4* __restr
             uint4* dst = out + ((v - drop.v0) * chunks_per_frame + chunk) * 2;
             dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
             dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ViT kernels (BASELINE configs[4]).
+// ---------------------------------------------------------------------------
+// Token assembly: x[f][0] = pos[0] (class token folded in), x[f][1+p] = bf16(emb[f*np + p] + pos[1+p]).
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const uint16_t* __restrict__ emb, const float* __restrict__ pos,
+                                                           uint16_t* __restrict__ x, int n, int ntok, int D) {
+    const long long total = (long long)n * ntok * (D / 4);
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % (D / 4));
+        const long long row = idx / (D / 4);
+        const int t = (int)(row % ntok);
+        const long long f = row / ntok;
+        const float4 pv = *(const float4*)(pos + (long long)t * D + c4 * 4);
+        float v0 = pv.x, v1 = pv.y, v2 = pv.z, v3 = pv.w;
+        if (t > 0) {
+            const uint2 e = *(const uint2*)(emb + ((f * (ntok - 1) + (t - 1)) * D + c4 * 4));
+            v0 = __fadd_rn(bf16_bits_to_f32(e.x & 0xFFFFu), v0); v1 = __fadd_rn(bf16_bits_to_f32(e.x >> 16), v1);
+            v2 = __fadd_rn(bf16_bits_to_f32(e.y & 0xFFFFu), v2); v3 = __fadd_rn(bf16_bits_to_f32(e.y >> 16), v3);
+        }
+        *(uint2*)(x + row * D + c4 * 4) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    }
+}
+
+// LayerNorm of bf16 rows (row r at x + r*ldx; D % 4 == 0, D <= 1024): one wave per row.  Lane l owns the
+// 4-element groups l, l+64, ...; sums are per-lane sequential, then a 6-level xor butterfly - the order
+// oracle/fav_exact.c: fav_layernorm_rows restates.  Statistics, scale and shift in fp32, one bf16 rounding.
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ x, long long ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ y, long long rows,
+                                                        int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ng = D >> 2;
+    const uint16_t* xr = x + row * ldx;
+    float v[4][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = lane + 64 * j;
+        if (g < ng) {
+            const uint2 e = *(const uint2*)(xr + 4 * g);
+            v[j][0] = bf16_bits_to_f32(e.x & 0xFFFFu); v[j][1] = bf16_bits_to_f32(e.x >> 16);
+            v[j][2] = bf16_bits_to_f32(e.y & 0xFFFFu); v[j][3] = bf16_bits_to_f32(e.y >> 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s = __fadd_rn(s, v[j][k]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s = __fadd_rn(s, __shfl_xor(s, o, 64));
+    const float mean = __fdiv_rn(s, (float)D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < ng) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[j][k] = __fsub_rn(v[j][k], mean);
+                s2 = __fadd_rn(s2, __fmul_rn(v[j][k], v[j][k]));
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 = __fadd_rn(s2, __shfl_xor(s2, o, 64));
+    const float var = __fdiv_rn(s2, (float)D);
+    const float rstd = __fdiv_rn(1.0f, fav_sqrtf(__fadd_rn(var, eps)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = lane + 64 * j;
+        if (g < ng) {
+            const float4 gm = *(const float4*)(gamma + 4 * g), bt = *(const float4*)(beta + 4 * g);
+            const float o0 = __fadd_rn(__fmul_rn(__fmul_rn(v[j][0], rstd), gm.x), bt.x);
+            const float o1 = __fadd_rn(__fmul_rn(__fmul_rn(v[j][1], rstd), gm.y), bt.y);
+            const float o2 = __fadd_rn(__fmul_rn(__fmul_rn(v[j][2], rstd), gm.z), bt.z);
+            const float o3 = __fadd_rn(__fmul_rn(__fmul_rn(v[j][3], rstd), gm.w), bt.w);
+            *(uint2*)(y + row * D + 4 * g) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
+    }
+}
+
+// Multi-head attention, head width 64, up to 256 tokens: one block (4 waves) per (frame, head).
+//   qkv [n][T][3D] bf16 (Q | K | V, head h = columns 64h..64h+63 of each)  ->  out [n][T][D] bf16
+// K (row-major, swizzled) and V^T live in LDS; a wave takes 16 queries at a time:
+//   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), x 1/8, keys >= T masked,
+//   row max / sum by the lane (sequential over its keys) and two xor-shuffles, e = fav_expf(s - max),
+//   p = e / sum rounded to bf16 through a per-wave LDS strip, O = V^T P^T on MFMA over keys ascending.
+// The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate.
+template <int MODE>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
+                                                        int heads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
+    const int nkt = (T + 15) >> 4;             // key tiles of 16
+    const int Tp2 = ((T + 31) >> 5) << 5;      // keys padded for the 32-deep second product
+    const int vstride = Tp2 * 2 + 16;          // bytes per V^T / P row (the +16 spreads rows over the banks)
+    unsigned char* const Ks = asm_;                                   // [nkt*16][128 B], chunk ^= row & 7
+    unsigned char* const Vt = Ks + nkt * 16 * 128;                    // [64][vstride]
+    unsigned char* const Ps = Vt + 64 * vstride;                      // [4 waves][16][vstride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.x % heads;
+    const long long f = blockIdx.x / heads;
+    const uint16_t* base = qkv + f * (long long)T * 3 * D;
+    // ---- stage K and V^T (zero beyond T) ----
+    for (int i = tid; i < nkt * 16 * 8; i += 256) {
+        const int row = i >> 3, ch = i & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < T) v = *(const uint4*)(base + (long long)row * 3 * D + D + h * 64 + ch * 8);
+        *(uint4*)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
+    }
+    for (int i = tid; i < Tp2 * 8; i += 256) {
+        const int key = i >> 3, ch = i & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (key < T) v = *(const uint4*)(base + (long long)key * 3 * D + 2 * D + h * 64 + ch * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(uint16_t*)(Vt + (ch * 8 + 2 * j) * vstride + key * 2) = (uint16_t)(w[j] & 0xFFFFu);
+            *(uint16_t*)(Vt + (ch * 8 + 2 * j + 1) * vstride + key * 2) = (uint16_t)(w[j] >> 16);
+        }
+    }
+    unsigned char* const Pw = Ps + wave * 16 * vstride;
+    for (int i = lane; i < 16 * (vstride / 16); i += 64) *(uint4*)(Pw + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    const int nqt = (T + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + frow;          // this lane's query (as MFMA column)
+        uint4 fqv[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            fqv[kk] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < T) fqv[kk] = *(const uint4*)(base + (long long)q * 3 * D + h * 64 + kk * 32 + fq * 8);
+        }
+        f32x4_t sc[16];
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+            sc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int row = kt * 16 + frow;
+                    const uint4 fk = *(const uint4*)(Ks + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+                    if (MODE == 0) {
+                        union { uint4 u; bf16x8_t v; } ua, ub;
+                        ua.u = fk; ub.u = fqv[kk];
+                        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, sc[kt], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t wa = ((const uint32_t*)&fk)[j >> 1], xa = ((const uint32_t*)&fqv[kk])[j >> 1];
+                            const float wf = bf16_bits_to_f32((j & 1) ? (wa >> 16) : (wa & 0xFFFFu));
+                            const float xf = bf16_bits_to_f32((j & 1) ? (xa >> 16) : (xa & 0xFFFFu));
+                            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf, sc[kt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // scale, mask, row max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt)
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + fq * 4 + r;
+                    const float v = key < T ? __fmul_rn(sc[kt][r], 0.125f) : -INFINITY;
+                    sc[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt)
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fav_expf(__fsub_rn(sc[kt][r], mx));
+                    sc[kt][r] = e;
+                    sum = __fadd_rn(sum, e);
+                }
+            }
+        sum = __fadd_rn(sum, __shfl_xor(sum, 16, 64));
+        sum = __fadd_rn(sum, __shfl_xor(sum, 32, 64));
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt)
+            if (kt < nkt) {
+                const float p0 = __fdiv_rn(sc[kt][0], sum), p1 = __fdiv_rn(sc[kt][1], sum);
+                const float p2 = __fdiv_rn(sc[kt][2], sum), p3 = __fdiv_rn(sc[kt][3], sum);
+                *(uint2*)(Pw + frow * vstride + (kt * 16 + fq * 4) * 2) = make_uint2(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3));
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is private to this wave: LDS ops are in order, no barrier
+        f32x4_t oc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < (Tp2 >> 5); ++ks) {
+            const uint4 fp = *(const uint4*)(Pw + frow * vstride + (ks * 32 + fq * 8) * 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 fv = *(const uint4*)(Vt + (dt * 16 + frow) * vstride + (ks * 32 + fq * 8) * 2);
+                if (MODE == 0) {
+                    union { uint4 u; bf16x8_t v; } ua, ub;
+                    ua.u = fv; ub.u = fp;
+                    oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, oc[dt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t wa = ((const uint32_t*)&fv)[j >> 1], xa = ((const uint32_t*)&fp)[j >> 1];
+                        const float wf = bf16_bits_to_f32((j & 1) ? (wa >> 16) : (wa & 0xFFFFu));
+                        const float xf = bf16_bits_to_f32((j & 1) ? (xa >> 16) : (xa & 0xFFFFu));
+                        oc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf, oc[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of the strip are done before the next tile overwrites it
+        if (q < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *(uint2*)(out + (f * T + q) * (long long)D + h * 64 + dt * 16 + fq * 4) =
+                    make_uint2(pack_bf16x2(oc[dt][0], oc[dt][1]), pack_bf16x2(oc[dt][2], oc[dt][3]));
         }
     }
 }

@@ -17,6 +17,13 @@ Blob layout (little endian):
   data         : per layer bf16 w[cout][kh][kw][cin] (BN scale folded in),
                  fp32 b[cout]
 Layer order: stem; per block conv1, conv2, (conv3), (downsample); fc.
+
+ViT checkpoints (arch "vit_b16", "vit_tiny") use the same container.  A table row with kh = 0
+is a pair of fp32 vectors of length cout (w_off -> first, b_off -> second): LayerNorm
+(gamma, beta), and the position table (pos[ntok][D] with the class token added into row 0;
+second vector unused).  Order: patch embedding (cout = D, cin = 3, kh = kw = stride = patch);
+position table; per block: ln1, qkv [3D][D] (rows Q | K | V, head h = columns 64h..64h+63 of
+each), proj, ln2, fc1, fc2; final ln; head.
 """
 from __future__ import annotations
 
@@ -28,7 +35,11 @@ import numpy as np
 from . import synth
 
 BLOB_MAGIC = 0x57564146
-ARCH_IDS = {"resnet18_cifar": 0, "resnet50": 1}
+ARCH_IDS = {"resnet18_cifar": 0, "resnet50": 1, "vit_b16": 2, "vit_tiny": 3}
+VIT_CFG = {  # embed dim, depth, heads (64-wide), MLP width, patch, default input
+    2: dict(dim=768, depth=12, heads=12, mlp=3072, patch=16, in_hw=(224, 224)),
+    3: dict(dim=128, depth=2, heads=2, mlp=256, patch=16, in_hw=(64, 64)),
+}
 _ARCH = {
     0: dict(block="basic", depths=(2, 2, 2, 2), planes=(64, 128, 256, 512), stem="cifar", calib_hw=32),
     1: dict(block="bottleneck", depths=(3, 4, 6, 3), planes=(64, 128, 256, 512), stem="imagenet", calib_hw=96),
@@ -66,15 +77,19 @@ def layer_specs(arch: int, num_classes: int):
 
 
 def n_blocks(arch: int) -> int:
+    if arch in VIT_CFG:
+        return 0
     return sum(_ARCH[arch]["depths"])
 
 
 def site_mask_for(arch: int, policy: str) -> int:
     """Dropout-site bitmask.  Site s < n_blocks is the output of residual block
     s; site n_blocks is the pooled feature vector feeding the classifier."""
-    nb = n_blocks(arch)
     if policy in ("none", "", None):
         return 0
+    if arch in VIT_CFG:
+        raise ValueError("the ViT path has no dropout sites (BASELINE configs[4] is a single pass)")
+    nb = n_blocks(arch)
     if policy == "last_layer":
         return 1 << nb
     if policy == "all_blocks":
@@ -111,6 +126,51 @@ def _conv64(x, w, stride, pad):
     cols = np.lib.stride_tricks.as_strided(
         xp, (b, ho, wo, kh, kw, c), (sb, sh * stride, sw * stride, sh, sw, sc), writeable=False)
     return (cols.reshape(b * ho * wo, -1) @ w.reshape(co, -1).T.astype(np.float64)).reshape(b, ho, wo, co)
+
+
+def make_synthetic_vit(arch="vit_b16", seed: int = 1, num_classes: int = 1000, in_hw=None,
+                       mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 5.0):
+    """Seeded synthetic ViT checkpoint (pre-norm encoder, class token, learned positions,
+    tanh-GELU MLP).  LayerNorm keeps activations in range, so no calibration pass is needed:
+    linear layers are N(0, 1/fan_in) (x0.5 where they feed the residual stream) and the head is
+    scaled for logits of standard deviation `logit_std`.  Returns (blob, info)."""
+    aid = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
+    cfg = VIT_CFG[aid]
+    D, depth, mlp, P = cfg["dim"], cfg["depth"], cfg["mlp"], cfg["patch"]
+    H, W = in_hw or cfg["in_hw"]
+    if H % P or W % P:
+        raise ValueError("ViT input must be a multiple of the patch size")
+    ntok = (H // P) * (W // P) + 1
+    rng = np.random.default_rng(seed)
+    specs, folded = [], []
+
+    def linear(cout, cin, gain, kh=1, kw=1, stride=1):
+        w = (rng.standard_normal((cout, kh, kw, cin)) * (gain / np.sqrt(kh * kw * cin))).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.02).astype(np.float32)
+        specs.append(dict(cout=cout, cin=cin, kh=kh, kw=kw, stride=stride, pad=0))
+        folded.append((_bf16(w), b))
+
+    def vectors(a, b):
+        specs.append(dict(cout=a.size, cin=0, kh=0, kw=0, stride=0, pad=0))
+        folded.append((np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)))
+
+    def layernorm():
+        vectors(1.0 + 0.1 * rng.standard_normal(D), 0.05 * rng.standard_normal(D))
+
+    linear(D, 3, 1.0, P, P, P)
+    pos = (0.2 * rng.standard_normal((ntok, D))).astype(np.float32)
+    pos[0] += (0.2 * rng.standard_normal(D)).astype(np.float32)   # class token
+    vectors(pos.reshape(-1), np.zeros(ntok * D, np.float32))
+    for _ in range(depth):
+        layernorm(); linear(3 * D, D, 1.0); linear(D, D, 0.5)
+        layernorm(); linear(mlp, D, 1.0); linear(D, mlp, 0.5)
+    layernorm()
+    linear(num_classes, D, logit_std)
+    folded[-1] = (folded[-1][0], np.zeros(num_classes, np.float32))
+    blob = pack_blob(aid, num_classes, specs, folded)
+    info = dict(arch=arch, num_classes=num_classes, n_layers=len(specs), seed=seed, in_hw=(H, W), n_tokens=ntok,
+                sha256=hashlib.sha256(blob).hexdigest(), mean=tuple(mean), std=tuple(std))
+    return blob, info
 
 
 def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = None,
@@ -219,7 +279,7 @@ def pack_blob(arch: int, num_classes: int, specs, folded) -> bytes:
     off = (off + 63) // 64 * 64
     table, chunks = [], []
     for sp, (wq, bq) in zip(specs, folded):
-        wb = np.ascontiguousarray(wq, np.uint16).tobytes()
+        wb = (np.ascontiguousarray(wq, np.float32) if sp["kh"] == 0 else np.ascontiguousarray(wq, np.uint16)).tobytes()
         w_off = off
         off = (off + len(wb) + 63) // 64 * 64
         bb = np.ascontiguousarray(bq, np.float32).tobytes()

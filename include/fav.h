@@ -49,7 +49,10 @@ typedef enum fav_status {
  * format (np.uint8 HxWx3, signal_analyzer.py:47-58; video_source.py:144-148);
  * NHWC_F32 carries [0,1] pixels (corrupted frames that are not 8-bit). */
 typedef enum fav_layout { FAV_LAYOUT_NHWC_U8 = 0, FAV_LAYOUT_NHWC_F32 = 1 } fav_layout;
-typedef enum fav_arch { FAV_ARCH_RESNET18_CIFAR = 0, FAV_ARCH_RESNET50 = 1 } fav_arch;
+/* FAV_ARCH_VIT_B16: ViT-B/16 (BASELINE configs[4]: attention path + temperature-scaled entropy; single pass,
+ * no dropout sites, no ensemble; input a multiple of 16 with at most 256 tokens).  FAV_ARCH_VIT_TINY: a
+ * two-layer, 128-wide miniature of it for the parity tests. */
+typedef enum fav_arch { FAV_ARCH_RESNET18_CIFAR = 0, FAV_ARCH_RESNET50 = 1, FAV_ARCH_VIT_B16 = 2, FAV_ARCH_VIT_TINY = 3 } fav_arch;
 typedef enum fav_conf_kind { FAV_CONF_MAX_SOFTMAX = 0, FAV_CONF_ENTROPY = 1 } fav_conf_kind;
 /* FAV_MATH_BF16: bf16 MFMA, fp32 accumulate (production).
  * FAV_MATH_F32_EXACT: same bf16 operands fed to the fp32-input MFMA, whose
@@ -161,7 +164,7 @@ typedef struct fav_conv_desc {
     const void* res;         /* optional [n_frames][Ho][Wo][Cout] bf16 */
     void* y;                 /* [n_frames][Ho][Wo][Cout] bf16, or fp32 if out_f32 */
     int32_t n_frames, H, W, Cin, Cout, kh, kw, stride, pad;
-    int32_t relu, out_f32, math_mode;
+    int32_t relu, out_f32, math_mode;   /* relu: 0 = none, 1 = ReLU, 2 = tanh-form GELU (ViT MLP) */
     fav_dropout_desc drop;
 } fav_conv_desc;
 fav_status fav_op_conv2d(const fav_conv_desc* d, void* hip_stream);
@@ -179,6 +182,19 @@ fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems_per_fram
 fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t num_classes, int32_t ld,
                        float temperature, int32_t conf_kind, float tau,
                        int32_t* labels, float* conf, uint8_t* fail, float* score, void* hip_stream);
+
+/* ---- ViT building blocks (BASELINE configs[4]); linear layers go through fav_op_conv2d with kh = kw = 1.
+ * LayerNorm over rows of D bf16 values (row r at x + r*ldx elements; D % 4 == 0, D <= 1024), fp32 statistics,
+ * y[rows][D] bf16. */
+fav_status fav_op_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t rows,
+                            int32_t D, float eps, void* hip_stream);
+/* Multi-head attention with 64-wide heads: qkv [n][T][3D] bf16 (Q | K | V) -> out [n][T][D] bf16,
+ * softmax(Q K^T / 8) V per head, T <= 256, D = 64 * heads. */
+fav_status fav_op_attention(const void* qkv, void* out, int32_t n, int32_t T, int32_t D, int32_t heads,
+                            int32_t math_mode, void* hip_stream);
+/* Token assembly: x[f][0] = pos[0], x[f][1 + p] = bf16(emb[f][p] + pos[1 + p]); emb [n][ntok-1][D] bf16, pos fp32. */
+fav_status fav_op_vit_assemble(const void* emb, const float* pos, void* x, int32_t n, int32_t ntok, int32_t D,
+                               void* hip_stream);
 
 /* ---- SignalAnalyzer.analyze_frame as one fused pass per frame (SURVEY.md §8f row 2;
  * reference platform/backend/signal_analyzer.py:62-112): cv2.COLOR_BGR2GRAY, cv2.Laplacian

@@ -248,3 +248,106 @@ void fav_bf16mfma_replay(const float* A, const float* Bt, const float* C, float*
                 D[((size_t)p * 16 + m) * 16 + n] =
                     fav_bf16mfma_dot32(A + ((size_t)p * 16 + m) * 32, Bt + ((size_t)p * 16 + n) * 32, C[((size_t)p * 16 + m) * 16 + n]);
 }
+
+/* ==========================================================================
+ * ViT pieces (BASELINE configs[4]): elementwise / row functions whose fp32 operation
+ * SEQUENCE is the specification - the HIP kernels (fav_kernels.hpp: fav_expf, fav_gelu,
+ * layernorm_kernel, attention_kernel) issue exactly these IEEE operations in exactly
+ * this order, so results are bit-identical.  Build with -ffp-contract=off: a contracted
+ * mul+add would change the bits.
+ * ========================================================================== */
+
+/* exp(x) = 2^k * p(r), k = rint(x * log2 e), r = x - k*ln2 (two-constant Cody-Waite, fused),
+ * p = degree-6 Taylor polynomial in Horner form with fused multiply-adds. */
+static inline float fav_expf_ref(float x) {
+    if (!(x >= -80.0f)) return 0.0f;            /* also NaN -> 0; keeps every result a normal number */
+    if (x > 88.0f) x = 88.0f;
+    const float k = rintf(x * 0x1.715476p+0f);
+    float r = fmaf(-k, 0x1.62e400p-1f, x);
+    r = fmaf(-k, 0x1.7f7d1cp-20f, r);
+    float p = 0x1.6c16c2p-10f;                  /* 1/720 */
+    p = fmaf(p, r, 0x1.111112p-7f);             /* 1/120 */
+    p = fmaf(p, r, 0x1.555556p-5f);             /* 1/24 */
+    p = fmaf(p, r, 0x1.555556p-3f);             /* 1/6 */
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return ldexpf(p, (int)k);
+}
+
+/* tanh-form GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), tanh(z) = 1 - 2 / (exp(2z) + 1) */
+static inline float fav_gelu_ref(float x) {
+    const float x3 = (x * x) * x;
+    const float inner = x + 0x1.6e4e26p-5f * x3;
+    const float z = 0x1.988454p-1f * inner;
+    const float e = fav_expf_ref(z + z);
+    const float t = 1.0f - 2.0f / (e + 1.0f);
+    return (0.5f * x) * (1.0f + t);
+}
+
+void fav_expf_arr(const float* x, float* y, long n) {
+#pragma omp parallel for
+    for (long i = 0; i < n; ++i) y[i] = fav_expf_ref(x[i]);
+}
+
+void fav_gelu_arr(const float* x, float* y, long n) {
+#pragma omp parallel for
+    for (long i = 0; i < n; ++i) y[i] = fav_gelu_ref(x[i]);
+}
+
+/* wave-shaped reduction: lane l sums its values in order, then a 6-level butterfly (xor 32..1) */
+static inline float wave_sum64(float* v) {
+    for (int o = 32; o >= 1; o >>= 1) {
+        float t[64];
+        for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ o];
+        for (int l = 0; l < 64; ++l) v[l] = t[l];
+    }
+    return v[0];
+}
+
+/* LayerNorm over rows of D (D % 4 == 0): lane l owns the 4-element groups l, l+64, l+128, ...
+ * y = ((x - mean) * rstd) * gamma + beta, every operation rounded separately (fp32 out). */
+void fav_layernorm_rows(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps) {
+    const int ng = D / 4;
+#pragma omp parallel for
+    for (long r = 0; r < rows; ++r) {
+        const float* xr = x + r * D;
+        float v[64];
+        for (int l = 0; l < 64; ++l) {
+            float s = 0.0f;
+            for (int g = l; g < ng; g += 64)
+                for (int e = 0; e < 4; ++e) s = s + xr[4 * g + e];
+            v[l] = s;
+        }
+        const float mean = wave_sum64(v) / (float)D;
+        for (int l = 0; l < 64; ++l) {
+            float s = 0.0f;
+            for (int g = l; g < ng; g += 64)
+                for (int e = 0; e < 4; ++e) { const float d = xr[4 * g + e] - mean; s = s + d * d; }
+            v[l] = s;
+        }
+        const float var = wave_sum64(v) / (float)D;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        for (int i = 0; i < D; ++i) y[r * D + i] = ((xr[i] - mean) * rstd) * gamma[i] + beta[i];
+    }
+}
+
+/* Attention softmax over rows of Tk scores (already scaled): the device holds, per query, keys
+ * kt*16 + 4*fq + r in lane group fq (0..3); each group sums exp() of its keys in ascending
+ * order, groups combine as (s0 + s1) + (s2 + s3).  p = e / sum. */
+void fav_attn_softmax_rows(const float* s, float* p, long rows, int Tk) {
+#pragma omp parallel for
+    for (long q = 0; q < rows; ++q) {
+        const float* sr = s + q * Tk;
+        float mx = -INFINITY;
+        for (int k = 0; k < Tk; ++k) mx = sr[k] > mx ? sr[k] : mx;
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < Tk; ++k) {
+            const float e = fav_expf_ref(sr[k] - mx);
+            p[q * Tk + k] = e;
+            part[(k >> 2) & 3] = part[(k >> 2) & 3] + e;
+        }
+        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+        for (int k = 0; k < Tk; ++k) p[q * Tk + k] = p[q * Tk + k] / sum;
+    }
+}

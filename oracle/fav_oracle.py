@@ -152,6 +152,10 @@ def parse_blob(blob: bytes) -> Model:
     m = Model(arch, ncls)
     for i in range(nlayers):
         cout, cin, kh, kw, stride, pad, _, _, w_off, b_off = struct.unpack_from("<8I2Q", blob, 32 + 48 * i)
+        if kh == 0:   # a pair of fp32 vectors (LayerNorm gamma/beta, ViT position table)
+            m.layers.append(ConvLayer(cout, 0, 0, 0, 0, 0, np.frombuffer(blob, np.float32, cout, w_off).copy(),
+                                      np.frombuffer(blob, np.float32, cout, b_off).copy()))
+            continue
         n = cout * kh * kw * cin
         w = bf16_from_bits(np.frombuffer(blob, np.uint16, n, w_off)).reshape(cout, kh, kw, cin)
         b = np.frombuffer(blob, np.float32, cout, b_off).copy()
@@ -201,6 +205,13 @@ def _exact_lib():
         for fn in (lib.fav_exact_conv_acc, lib.fav_bf16mfma_conv_acc):
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 9
+        for fn in (lib.fav_expf_arr, lib.fav_gelu_arr):
+            fn.restype = None
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        lib.fav_layernorm_rows.restype = None
+        lib.fav_layernorm_rows.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_int, ctypes.c_float]
+        lib.fav_attn_softmax_rows.restype = None
+        lib.fav_attn_softmax_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
         lib.fav_bf16mfma_replay.restype = None
         lib.fav_bf16mfma_replay.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int]
         _EXACT_LIB = lib
@@ -430,6 +441,130 @@ CONF_MAX_SOFTMAX = 0
 CONF_ENTROPY = 1
 
 
+
+# ----------------------------------------------------------------------------
+# ViT-B/16 (BASELINE configs[4]).  Build-defined like the rest (PARITY UNPINNED): pre-norm
+# encoder, class token, learned positions, tanh-GELU MLP, bf16 at every tensor boundary,
+# fp32 accumulation / statistics.  exp, GELU, LayerNorm and the attention softmax are the
+# exact fp32 operation sequences of oracle/fav_exact.c, which the HIP kernels repeat.
+# ----------------------------------------------------------------------------
+ARCH_VIT_B16 = 2
+ARCH_VIT_TINY = 3
+VIT_CFG = {ARCH_VIT_B16: dict(dim=768, depth=12, heads=12, mlp=3072, patch=16),
+           ARCH_VIT_TINY: dict(dim=128, depth=2, heads=2, mlp=256, patch=16)}
+LN_EPS = np.float32(1e-6)
+
+
+def _c_unary(name, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    getattr(_exact_lib(), name)(x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
+def expf_exact(x):
+    return _c_unary("fav_expf_arr", x)
+
+
+def gelu_exact(x):
+    return _c_unary("fav_gelu_arr", x)
+
+
+def layernorm_exact(x, gamma, beta, eps=LN_EPS):
+    """fp32 LayerNorm over the last axis in the device's reduction order (not yet rounded to bf16)."""
+    x = np.ascontiguousarray(x, np.float32)
+    d = x.shape[-1]
+    y = np.empty_like(x)
+    g, b = np.ascontiguousarray(gamma, np.float32), np.ascontiguousarray(beta, np.float32)
+    _exact_lib().fav_layernorm_rows(x.ctypes.data, g.ctypes.data, b.ctypes.data, y.ctypes.data, x.size // d, d, float(eps))
+    return y
+
+
+def attn_softmax_exact(s):
+    s = np.ascontiguousarray(s, np.float32)
+    p = np.empty_like(s)
+    _exact_lib().fav_attn_softmax_rows(s.ctypes.data, p.ctypes.data, s.size // s.shape[-1], s.shape[-1])
+    return p
+
+
+def gemm_acc(a, w, exact=False):
+    """fp32 accumulator a[M,K] @ w[N,K]^T in the chosen summation model (K zero-padded to 64)."""
+    a = np.ascontiguousarray(a, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    if not exact:
+        return (a @ w.T).astype(np.float32)
+    m, k = a.shape
+    kp = (k + 63) // 64 * 64
+    if kp != k:
+        a = np.concatenate([a, np.zeros((m, kp - k), np.float32)], axis=1)
+        w = np.concatenate([w, np.zeros((w.shape[0], kp - k), np.float32)], axis=1)
+    return conv_acc_exact(a.reshape(1, m, 1, kp), w.reshape(w.shape[0], 1, 1, kp), 1, 1, 1, 0, exact).reshape(m, w.shape[0])
+
+
+def attention(qkv, heads, exact=False):
+    """qkv [B, T, 3D] bf16 values -> [B, T, D] bf16: per head softmax(Q K^T / 8) V with fp32
+    scores, probabilities rounded to bf16 before the second product."""
+    b, t, d3 = qkv.shape
+    d = d3 // 3
+    out = np.empty((b, t, d), np.float32)
+    for i in range(b):
+        for h in range(heads):
+            q = qkv[i, :, h * 64:(h + 1) * 64]
+            k = qkv[i, :, d + h * 64:d + (h + 1) * 64]
+            v = qkv[i, :, 2 * d + h * 64:2 * d + (h + 1) * 64]
+            s = gemm_acc(q, k, exact) * np.float32(0.125)
+            p = bf16_round(attn_softmax_exact(s))
+            out[i, :, h * 64:(h + 1) * 64] = bf16_round(gemm_acc(p, np.ascontiguousarray(v.T), exact))
+    return out
+
+
+class VitNet:
+    def __init__(self, model: Model, exact=False):
+        self.m, self.exact = model, exact
+        self.cfg = VIT_CFG[model.arch]
+        self.trace = None
+
+    def _lin(self, x, L, res=None, act=None):
+        y = gemm_acc(x.reshape(-1, x.shape[-1]), L.w.reshape(L.cout, -1), self.exact) + L.b
+        if res is not None:
+            y = y + res.reshape(-1, L.cout)
+        if act == "gelu":
+            y = gelu_exact(y)
+        return y.reshape(x.shape[:-1] + (L.cout,)).astype(np.float32)
+
+    def _ln(self, x, L):
+        return bf16_round(layernorm_exact(x, L.w, L.b))
+
+    def forward_logits(self, xn, *unused, **unused_kw):
+        c, Ls = self.cfg, self.m.layers
+        b, hh, ww, _ = xn.shape
+        p, d = c["patch"], c["dim"]
+        gh, gw = hh // p, ww // p
+        patches = xn.reshape(b, gh, p, gw, p, 3).transpose(0, 1, 3, 2, 4, 5).reshape(b, gh * gw, p * p * 3)
+        emb = bf16_round(self._lin(patches, Ls[0]))
+        pos = Ls[1].w.reshape(-1, d)
+        if pos.shape[0] != gh * gw + 1:
+            raise ValueError("position table does not match the input size")
+        x = np.empty((b, gh * gw + 1, d), np.float32)
+        x[:, 0] = pos[0]
+        x[:, 1:] = emb + pos[1:]
+        x = bf16_round(x)
+        li = 2
+        for _ in range(c["depth"]):
+            ln1, qkv, proj, ln2, fc1, fc2 = Ls[li:li + 6]
+            li += 6
+            y = self._ln(x, ln1)
+            a = attention(bf16_round(self._lin(y, qkv)), c["heads"], self.exact)
+            x = bf16_round(self._lin(a, proj, res=x))
+            y = self._ln(x, ln2)
+            hdn = bf16_round(self._lin(y, fc1, act="gelu"))
+            x = bf16_round(self._lin(hdn, fc2, res=x))
+            if self.trace is not None:
+                self.trace.append(x.copy())
+        y = self._ln(x[:, 0], Ls[li])
+        return self._lin(y, Ls[li + 1])[None]
+
+
 def mean_softmax(logits: np.ndarray, temperature: float = 1.0) -> np.ndarray:
     """logits [T,B,C] fp32 -> mean over T of softmax(z * fp32(1/temp)), fp32 [B,C]."""
     z = logits.astype(np.float32) * np.float32(1.0 / temperature)
@@ -487,7 +622,7 @@ def inv_std32(std):
 
 
 def classify(model: Model, images: np.ndarray, cfg: ClassifyConfig, img_ids=None, return_logits=False):
-    net = OracleNet(model, exact=cfg.exact)
+    net = VitNet(model, exact=cfg.exact) if model.arch in VIT_CFG else OracleNet(model, exact=cfg.exact)
     xn = normalize_input(images, cfg.mean, inv_std32(cfg.std))
     lg = net.forward_logits(xn, img_ids, cfg.n_samples, cfg.site_mask, cfg.p, cfg.seed)
     labels, conf, pbar = confidence_head(lg, cfg.temperature, cfg.conf_kind)
