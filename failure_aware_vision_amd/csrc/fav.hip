@@ -231,8 +231,10 @@ int conv_bm(int kh, int kw, long long M) {
 // when Cout % 256 == 0, unset = the measured rule.
 bool conv_big(int kh, int kw, long long M, int cout_pad, int K, bool has_res) {
     static int mode = [] { const char* e = getenv("FAV_CONV_BIG"); return e ? atoi(e) : 2; }();
-    if (mode == 0 || cout_pad % 256 != 0 || M < 16384) return false;
+    static long long min_m = [] { const char* e = getenv("FAV_CONV_BIG_MINM"); return e ? atoll(e) : 8192ll; }();
+    if (mode == 0 || cout_pad % 256 != 0 || M < min_m) return false;
     if (mode == 1) return true;
+    if ((M / 256) * (cout_pad / 256) < 512) return false;   // fewer than two 256x256 tiles per CU: 128-row tiles fill the chip better
     return kh * kw > 1 ? !has_res : K >= 512;
 }
 
@@ -440,7 +442,7 @@ const char* launch_layernorm(fav_handle* h, const void* x, long long ldx, const 
 const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, int T, int D, int heads, int math_mode, hipStream_t s) {
     if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
     const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
-    const int lds = nkt * 16 * 128 + 64 * vstride + 4 * 16 * vstride;
+    const int lds = nkt * 16 * 128 + 64 * vstride + 8 * 16 * vstride;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -451,9 +453,9 @@ const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, i
     const double flops = 4.0 * n * heads * (double)T * T * 64;
     Prof pr(h, s, FAV_K_CONV, flops, (double)n * T * D * 2 * 4);
     if (math_mode == FAV_MATH_BF16)
-        hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)(n * heads)), dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+        hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)(n * heads)), dim3(512), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
     else
-        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)(n * heads)), dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)(n * heads)), dim3(512), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
     return nullptr;
 }
 

@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     }
 }
 
-// Multi-head attention, head width 64, up to 256 tokens: one block (4 waves) per (frame, head).
+// Multi-head attention, head width 64, up to 256 tokens: one block (8 waves) per (frame, head).
 //   qkv [n][T][3D] bf16 (Q | K | V, head h = columns 64h..64h+63 of each)  ->  out [n][T][D] bf16
 // K (row-major, swizzled) and V^T live in LDS; a wave takes 16 queries at a time:
 //   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), x 1/8, keys >= T masked,
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 //   p = e / sum rounded to bf16 through a per-wave LDS strip, O = V^T P^T on MFMA over keys ascending.
 // The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate.
 template <int MODE>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
+__global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
                                                         int heads) {
     extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
     const int nkt = (T + 15) >> 4;             // key tiles of 16
@@ -1058,20 +1058,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int vstride = Tp2 * 2 + 16;          // bytes per V^T / P row (the +16 spreads rows over the banks)
     unsigned char* const Ks = asm_;                                   // [nkt*16][128 B], chunk ^= row & 7
     unsigned char* const Vt = Ks + nkt * 16 * 128;                    // [64][vstride]
-    unsigned char* const Ps = Vt + 64 * vstride;                      // [4 waves][16][vstride]
+    unsigned char* const Ps = Vt + 64 * vstride;                      // [8 waves][16][vstride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int h = blockIdx.x % heads;
     const long long f = blockIdx.x / heads;
     const uint16_t* base = qkv + f * (long long)T * 3 * D;
     // ---- stage K and V^T (zero beyond T) ----
-    for (int i = tid; i < nkt * 16 * 8; i += 256) {
+    for (int i = tid; i < nkt * 16 * 8; i += 512) {
         const int row = i >> 3, ch = i & 7;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < T) v = *(const uint4*)(base + (long long)row * 3 * D + D + h * 64 + ch * 8);
         *(uint4*)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
     }
-    for (int i = tid; i < Tp2 * 8; i += 256) {
+    for (int i = tid; i < Tp2 * 8; i += 512) {
         const int key = i >> 3, ch = i & 7;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (key < T) v = *(const uint4*)(base + (long long)key * 3 * D + 2 * D + h * 64 + ch * 8);
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     __syncthreads();
 
     const int nqt = (T + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += 8) {
         const int q = qt * 16 + frow;          // this lane's query (as MFMA column)
         uint4 fqv[2];
 #pragma unroll

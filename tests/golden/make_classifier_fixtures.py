@@ -6,6 +6,7 @@ the fixtures hold only expected outputs.
   python tests/golden/make_classifier_fixtures.py 10k     # 10,000 frames, single pass  (~1 h on 8 cores)
   python tests/golden/make_classifier_fixtures.py mfma_mc # 16 frames, T=30 all_blocks, production bf16-MFMA model
   python tests/golden/make_classifier_fixtures.py mfma_1k # 1,000 frames, single pass, production bf16-MFMA model
+  python tests/golden/make_classifier_fixtures.py vit     # ViT-B/16, 16 corrupted frames, production bf16-MFMA model
 """
 import os, sys, time, zlib
 import numpy as np
@@ -16,7 +17,11 @@ from oracle import fav_oracle as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FRAME_SEED, NOISE_SEED, SEVERITY = 21, 3, 3
-blob, info = weights.make_synthetic("resnet50", seed=1)
+what = sys.argv[1] if len(sys.argv) > 1 else "mc"
+if what == "vit":
+    blob, info = weights.make_synthetic_vit("vit_b16", seed=1)
+else:
+    blob, info = weights.make_synthetic("resnet50", seed=1)
 model = O.parse_blob(blob)
 
 
@@ -36,8 +41,21 @@ def gap_of(pbar):
     return (s[:, -1] - s[:, -2]).astype(np.float32)
 
 
-what = sys.argv[1] if len(sys.argv) > 1 else "mc"
-if what == "mc":
+if what == "vit":
+    n = 16
+    cfg = O.ClassifyConfig(exact="mfma", temperature=1.5, conf_kind=O.CONF_ENTROPY)
+    labels, conf, gaps, crcs = [], [], [], []
+    for s in range(0, n, 4):
+        t0 = time.time()
+        l, c, lg, pb = O.classify(model, frames(s, 4), cfg, return_logits=True)
+        labels.append(l); conf.append(c); gaps.append(gap_of(pb)); crcs.append(frame_crc(lg))
+        print("vit", s, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "vit_b16_mfma_16.npz"), labels=np.concatenate(labels).astype(np.int16),
+                        conf=np.concatenate(conf), gap=np.concatenate(gaps), logit_crc32=np.concatenate(crcs),
+                        blob_sha256=info["sha256"],
+                        meta="vit_b16 seed1; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; single pass, entropy "
+                             "confidence at temperature 1.5; production mode (v_mfma_f32_16x16x32_bf16 model)")
+elif what == "mc":
     n, T = 64, 30
     cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact=True)
     labels, conf, gaps = [], [], []

@@ -75,6 +75,23 @@ def test_production_mode_thousand_corrupted_frames(r50_blob):
     be.close()
 
 
+def test_vit_b16_production_mode_fixture():
+    """BASELINE configs[4]: ViT-B/16 on 16 corrupted 224x224 frames, entropy confidence at temperature 1.5,
+    PRODUCTION bf16 mode: every logit bit-identical to the fixture (per-frame CRC-32), labels exactly equal."""
+    from failure_aware_vision_amd import weights
+    blob, info = weights.make_synthetic_vit("vit_b16", seed=1)
+    d = load("vit_b16_mfma_16.npz", info)
+    n = len(d["labels"])
+    be = Backend("vit_b16", blob, max_batch=n, temperature=1.5, conf_kind="entropy")
+    labels, conf = be.classify(frames(0, n))
+    assert np.array_equal(frame_crc(be.logits()), d["logit_crc32"])
+    tie = d["gap"] < 1e-6
+    assert np.array_equal(labels.cpu().numpy()[~tie], d["labels"].astype(np.int32)[~tie])
+    np.testing.assert_allclose(conf.cpu().numpy(), d["conf"], rtol=0, atol=3e-6)
+    assert len(np.unique(d["labels"])) >= 3
+    be.close()
+
+
 def test_mc_dropout_t30_fixture(r50_blob):
     """BASELINE configs[2] exactly (T=30, all_blocks, p=0.1, noise severity 3) on 64 frames."""
     blob, info = r50_blob
