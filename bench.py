@@ -181,7 +181,7 @@ def main():
             out["roofline_mfma"] = dict(common, bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                                         frac=tf / PEAK_BF16_TFLOPS, traffic=None)
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(blob, args, T, args.policy)
                 out["gpu_over_cpu"] = fps / world / out["cpu_baseline"]["value"]
