@@ -204,7 +204,7 @@ DropParams make_drop(const fav_dropout_desc* d) {
 int conv_bk(int kh, int kw, int K, bool has_res) {
     static int forced = [] { const char* e = getenv("FAV_CONV_BK"); return e ? atoi(e) : 0; }();
     if (forced == 32 || forced == 64) return forced;
-    return (kh * kw > 1 || (!has_res && K >= 512)) ? 64 : 32;
+    return (kh * kw > 1 || (!has_res && K >= 512) || K >= 1024) ? 64 : 32;   // K >= 1024 with a residual: the ViT MLP's second GEMM
 }
 
 int conv_ns(int bk) {
