@@ -175,8 +175,11 @@ def main():
                       "timing": "HIP events recorded on the launch stream around every launch, inside the timed region"}
             # The unfused layer-by-layer workload is HBM-bound overall (186 FLOP/B algorithmic vs
             # 312 FLOP/B machine balance), so the binding roofline is HBM.
+            tr = pmc_traffic()
             out["roofline"] = dict(common, bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
-                                   frac=gbs / PEAK_HBM_GBS, traffic=pmc_traffic(),
+                                   frac=gbs / PEAK_HBM_GBS,
+                                   traffic=tr["bytes_per_launch"] if tr else None,   # HBM bytes per launch from the PMC passes
+                                   traffic_detail=tr,
                                    algorithmic_bytes_per_launch=cv["bytes"] / max(1, cv["launches"]))
             out["roofline_mfma"] = dict(common, bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                                         frac=tf / PEAK_BF16_TFLOPS, traffic=None)
