@@ -128,3 +128,47 @@ def test_sharded_classify_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def _build_c_example(tmp_path):
+    exe = str(tmp_path / "classify_host")
+    libdir = os.path.join(ROOT, "failure_aware_vision_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "classify_host.c"), "-o", exe, "-L" + libdir, "-lfav_hip",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_plain_c_caller_links_and_reports_missing_gpu(lib, tmp_path):
+    """include/fav.h is C99-clean and a C program links against the library; without a GPU it gets
+    FAV_ERR_NO_DEVICE (5) and the 'no CPU fallback' message, not a crash."""
+    import torch
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 64 and "ABI version 1" in r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the classify run is covered by the gpu-marked test")
+    (tmp_path / "w.favw").write_bytes(b"\0" * 64)
+    (tmp_path / "f.u8").write_bytes(b"\0" * (32 * 32 * 3))
+    r = subprocess.run([exe, "0", str(tmp_path / "w.favw"), str(tmp_path / "f.u8"), "1", "32", "32"], capture_output=True, text=True)
+    assert r.returncode == 5 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_matches_python_backend(lib, tmp_path):
+    """The same frames through a plain-C host and through the Python Backend: identical labels and confidences."""
+    import torch
+    from failure_aware_vision_amd import Backend, synth, weights
+    exe = _build_c_example(tmp_path)
+    blob, _ = weights.make_synthetic("resnet18_cifar", seed=1)
+    frames = synth.synthetic_frames_u8(6, 32, 32, seed=11)
+    (tmp_path / "w.favw").write_bytes(blob)
+    (tmp_path / "f.u8").write_bytes(frames.tobytes())
+    r = subprocess.run([exe, "0", str(tmp_path / "w.favw"), str(tmp_path / "f.u8"), "6", "32", "32"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split() for ln in r.stdout.strip().splitlines()]
+    be = Backend("resnet18_cifar", blob, max_batch=6)
+    labels, conf = be.classify(torch.from_numpy(frames).cuda())
+    be.close()
+    assert [int(x[0]) for x in rows] == labels.cpu().tolist()
+    assert np.allclose([float(x[1]) for x in rows], conf.cpu().numpy(), rtol=0, atol=1e-7)
