@@ -179,14 +179,14 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
 // addresses and zero fill for padding taps; weights are [Cout][K] so both MFMA
 // operands are K-contiguous.
 //
-// Block: 256 threads = 4 waves (2 x 2), tile BM x BN x 64, LDS double buffer
-// with the (chunk ^ row&7) XOR swizzle so the ds_read_b128 fragment reads are
-// bank-conflict free.  MFMA orientation: A-operand = weights (rows n), B-operand
-// = activations (cols m), so a lane's 4 accumulator registers are 4 consecutive
+// Block: (BM/64) x WN waves (4 for the 128-row tiles, 8 for 256 x 256), tile BM x BN x BK with BK = 32
+// or 64 channels of one tap, an NS-stage LDS ring filled by LDS-DMA, and an XOR swizzle on the staged rows
+// so the ds_read_b128 fragment reads are bank-conflict free.  MFMA orientation: A-operand = weights
+// (rows n), B-operand = activations (cols m), so a lane's 4 accumulator registers are 4 consecutive
 // output channels of one output pixel -> one 16-B LDS write in the epilogue.
-// Epilogue: fp32 tile staged through LDS, then row-major 8-channel chunks:
-// ((acc + bias) + residual) -> ReLU -> dropout -> one bf16 rounding -> 16-B
-// coalesced stores.
+// Epilogue: fp32 tile staged through LDS 64 rows at a time, then 16 consecutive channels per thread:
+// ((acc + bias) + residual) -> ReLU / GELU -> dropout -> one bf16 rounding -> two 16-B stores; every
+// global load of the epilogue (bias, residual) is issued BEFORE the K loop (see the comments there).
 // ---------------------------------------------------------------------------
 // One LDS-DMA piece: buffer_load_dwordx4 ... lds moves 64 lanes x 16 B from
 // (descriptor base + per-lane voffset + uniform soffset) to 1 KiB of LDS at the
