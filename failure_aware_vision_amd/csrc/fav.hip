@@ -380,6 +380,19 @@ void launch_stem(fav_handle* h, const void* images, int layout, int n, int H, in
     const int Ho = conv_out(H, kh, stride, pad), Wo = conv_out(W, kw, stride, pad);
     const long long total = (long long)n * Ho * Wo * (kpad / 8);
     Prof pr(h, s, FAV_K_STEM, 0.0, (double)n * H * W * 3 * (layout == 0 ? 1 : 4) + (double)total * 16);
+    const long long total_pix = (long long)n * Ho * Wo;
+    const int ppb = kh <= 64 ? 256 / kh : 0;                    // pixels per block of the row-wise kernel
+    const size_t lds = (size_t)ppb * kpad * 2;
+    if (ppb >= 4 && lds <= 64 * 1024 && total_pix / ppb < (1ll << 31) - 1) {
+        const unsigned blocks = (unsigned)((total_pix + ppb - 1) / ppb);
+        if (layout == FAV_LAYOUT_NHWC_U8)
+            hipLaunchKernelGGL((stem_im2col_rows_kernel<0>), dim3(blocks), dim3(256), lds, s, images, (uint4*)out, total_pix, H, W, Ho, Wo,
+                               kh, kw, stride, pad, kpad, ppb, mean[0], mean[1], mean[2], istd[0], istd[1], istd[2]);
+        else
+            hipLaunchKernelGGL((stem_im2col_rows_kernel<1>), dim3(blocks), dim3(256), lds, s, images, (uint4*)out, total_pix, H, W, Ho, Wo,
+                               kh, kw, stride, pad, kpad, ppb, mean[0], mean[1], mean[2], istd[0], istd[1], istd[2]);
+        return;
+    }
     if (layout == FAV_LAYOUT_NHWC_U8)
         hipLaunchKernelGGL((stem_im2col_kernel<0>), dim3(grid_for(total)), dim3(256), 0, s, images, (uint4*)out, n, H, W,
                            Ho, Wo, kh, kw, stride, pad, kpad, mean[0], mean[1], mean[2], istd[0], istd[1], istd[2]);

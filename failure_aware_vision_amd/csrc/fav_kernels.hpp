@@ -171,6 +171,56 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
     }
 }
 
+// Row-wise variant (the one the launcher uses): a thread owns one tap row r of one output pixel, i.e.
+// kw*3 values that are CONTIGUOUS both in the NHWC3 image (row ih, columns iw0 .. iw0+kw-1) and in k,
+// normalises them into an LDS row [pixel][kpad], and the block then writes its pixels' rows with coalesced
+// 16-B stores.  No per-element division: 0.95 -> ~0.3 ms for the 7x7/2 stem of 256 frames (the element-wise
+// kernel above spends ~50 integer instructions per value on index arithmetic).
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void stem_im2col_rows_kernel(const void* __restrict__ images, uint4* __restrict__ out,
+                                                               long long total_pix, int H, int W, int Ho, int Wo, int kh, int kw,
+                                                               int stride, int pad, int kpad, int ppb, float m0, float m1, float m2,
+                                                               float i0, float i1, float i2) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t rows_s[];   // [ppb][kpad]
+    const int tid = threadIdx.x;
+    const int K = kh * kw * 3;
+    const long long pix0 = (long long)blockIdx.x * ppb;
+    for (int i = tid; i < ppb * (kpad - K); i += 256) rows_s[(i / (kpad - K)) * kpad + K + i % (kpad - K)] = 0;
+    const int pl = tid / kh, r = tid - pl * kh;
+    const long long pixel = pix0 + pl;
+    if (pl < ppb && pixel < total_pix) {
+        const long long img = pixel / ((long long)Ho * Wo);
+        const int rem = (int)(pixel - img * (long long)Ho * Wo);
+        const int oh = rem / Wo, ow = rem - oh * Wo;
+        const int ih = oh * stride - pad + r, iw0 = ow * stride - pad;
+        const bool rowok = (unsigned)ih < (unsigned)H;
+        const long long base = ((img * H + ih) * W + iw0) * 3;
+        uint16_t* dst = rows_s + pl * kpad + r * kw * 3;
+        for (int sx = 0; sx < kw; ++sx) {
+            const bool ok = rowok && (unsigned)(iw0 + sx) < (unsigned)W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float val = 0.f;
+                if (ok) {
+                    float px;
+                    if (LAYOUT == 0) px = __fmul_rn((float)((const uint8_t*)images)[base + sx * 3 + c], 1.0f / 255.0f);
+                    else px = ((const float*)images)[base + sx * 3 + c];
+                    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+                    const float istd = c == 0 ? i0 : (c == 1 ? i1 : i2);
+                    val = __fmul_rn(__fsub_rn(px, mean), istd);
+                }
+                dst[sx * 3 + c] = (uint16_t)f32_to_bf16_bits(val);
+            }
+        }
+    }
+    __syncthreads();
+    const int cpr = kpad >> 3;   // 16-B chunks per row
+    for (int i = tid; i < ppb * cpr; i += 256) {
+        const long long pixel2 = pix0 + i / cpr;
+        if (pixel2 < total_pix) out[pixel2 * cpr + (i % cpr)] = *(const uint4*)(rows_s + (size_t)i * 8);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Convolution as implicit-im2col GEMM on MFMA.
 //   Y[m, n] = sum_k A[m, k] * Wt[n, k],  m = (frame, oh, ow), k = (r, s, c)
