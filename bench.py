@@ -10,14 +10,21 @@ frame.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), eve
 rank classifies its own 256-frame shard of a 256*N global batch (weak scaling) and
 the packed (label, confidence) records are all-gathered.
 
+`python bench.py --gpus N` with no torchrun environment starts the N ranks itself
+(a child `python -m torch.distributed.run ... bench.py`), BEFORE this process has
+imported torch or touched the GPU, and exits with the child's return code.
+
 Prints ONE JSON line on rank 0 (see README / DESIGN.md §6 for the fields).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -26,8 +33,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 RESNET50_GMAC = 4.089  # per frame, single pass
+VIT_B16_GMAC = 17.56
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+KERNEL_SOURCES = ("failure_aware_vision_amd/csrc/fav_kernels.hpp", "failure_aware_vision_amd/csrc/fav.hip")
 
 
 def algorithmic_gflop_per_frame(policy: str, T: int) -> float:
@@ -37,22 +46,48 @@ def algorithmic_gflop_per_frame(policy: str, T: int) -> float:
     return 2 * (prefix + T * (RESNET50_GMAC - prefix))
 
 
+def kernel_source_sha() -> str:
+    """SHA-256 over the kernel sources a PMC profile was measured on (profiles/pmc_traffic.json records it)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic():
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of the same command
     (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; separate
-    passes; tools/profile.sh -> profiles/pmc_traffic.json).  None when no profile is committed."""
+    passes; tools/profile.sh -> profiles/pmc_traffic.json).  The file records the SHA-256 of the
+    kernel sources it was measured on; when that no longer matches the sources in this tree the
+    figure is stale and None is reported (the roofline line then says `traffic: null`)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(path))
+        if d.get("kernel_source_sha256") != kernel_source_sha():
+            return {"stale": True, "measured_on": d.get("kernel_source_sha256"), "source": d.get("source")}
         return {"bytes_per_launch": d["conv_bytes_per_launch"], "fetch_bytes_per_launch": d["conv_fetch_bytes_per_launch"],
-                "write_bytes_per_launch": d["conv_write_bytes_per_launch"], "source": d["source"]}
+                "write_bytes_per_launch": d["conv_write_bytes_per_launch"], "source": d["source"],
+                "kernel_source_sha256": d["kernel_source_sha256"]}
     except Exception:
         return None
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(blob, args, T, policy):
-    """The oracle's torch-CPU port on a bounded sample of the same workload (same
-    weights, corruption, masks and prefix caching), timed on this host's cores."""
+    """The oracle's torch-CPU port (fp32 MKL-DNN, same weights, corruption, masks and prefix caching) on a
+    bounded sample of the same workload, timed on this host's cores: `cpu_frames` frames x T samples, the T
+    suffix passes stacked into one batch (what a many-core host runs best), one warm-up call - which also
+    generates the Philox masks, so they are inputs, outside the timed region - then `cpu_repeats` timed calls."""
     import torch
     from failure_aware_vision_amd import synth, weights
     from oracle import fav_oracle as O
@@ -61,16 +96,86 @@ def cpu_baseline(blob, args, T, policy):
     frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(n, 224, 224, seed=21), 3, seed=3)
     model = O.parse_blob(blob)
     net = TC.TorchNet(model)
+    net.mask_cache = {}
     cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, policy), p=args.dropout_p, seed=4)
     t0 = time.perf_counter()
-    TC.classify(model, frames, cfg, net=net)
-    dt = time.perf_counter() - t0
+    TC.classify(model, frames, cfg, net=net, stack_samples=True)          # warm-up + mask generation
+    warm = time.perf_counter() - t0
+    times = []
+    for _ in range(max(1, args.cpu_repeats)):
+        t0 = time.perf_counter()
+        TC.classify(model, frames, cfg, net=net, stack_samples=True)
+        times.append(time.perf_counter() - t0)
+        if sum(times) > 45.0:                                               # keep the default run within minutes
+            break
+    dt = statistics.median(times)
+    gf = algorithmic_gflop_per_frame(policy, T)
     return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} frames x T={T} ({policy}), oracle/torch_cpu.py fp32 MKL-DNN, one timed call of {dt:.1f} s",
-            "seconds": dt}
+            "batch": n, "repeats": len(times), "seconds": times, "warmup_seconds": warm,
+            "gflops": n * gf / dt, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"{n} frames x T={T} ({policy}) = {n * T} suffix passes in one stacked batch, oracle/torch_cpu.py "
+                      f"fp32 MKL-DNN on {torch.get_num_threads()} threads; 1 warm-up call (also generates the Philox "
+                      f"masks: inputs, not timed) + {len(times)} timed calls, median {dt:.2f} s"}
 
 
-def main():
+def secondary_configs(blob, args, torch, synth, weights, Backend):
+    """Cheap driver-timed lines for the other BASELINE configs (1 GPU, after the headline's timed region):
+    configs[1] single pass, configs[3]'s per-GPU share (5 members, 32 frames), configs[4]'s per-GPU share
+    (ViT-B/16, 64 frames).  fps = frames / wall time of `steps` calls bracketed by synchronize()."""
+    out = {}
+
+    def timed(be, frames, steps, warm=2):
+        for _ in range(warm):
+            be.classify(frames)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            be.classify(frames)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    u8 = synth.synthetic_frames_u8(256, 224, 224, seed=21)
+    frames = torch.from_numpy(synth.gaussian_noise_f32(u8, 3, seed=3)).cuda()
+    try:
+        be = Backend("resnet50", blob, max_batch=256)
+        dt = timed(be, frames, 10)
+        be.close()
+        out["single_pass"] = {"config": "BASELINE configs[1]: ResNet-50 224x224 batch 256, single pass", "frames_per_s": 256 / dt,
+                              "ms_per_call": dt * 1e3, "tflops": 256 * 2 * RESNET50_GMAC / dt / 1e3}
+    except Exception as e:
+        out["single_pass"] = {"error": str(e)}
+    try:
+        members = [blob] + [weights.make_synthetic("resnet50", seed=s)[0] for s in (2, 3, 4, 5)]
+        be = Backend("resnet50", members, max_batch=32)
+        dt = timed(be, frames[:32], 10)
+        be.close()
+        out["ensemble5@32"] = {"config": "BASELINE configs[3] per-GPU share: 5 x ResNet-50 members, 32 frames per call",
+                               "frames_per_s": 32 / dt, "ms_per_call": dt * 1e3, "tflops": 32 * 5 * 2 * RESNET50_GMAC / dt / 1e3}
+    except Exception as e:
+        out["ensemble5@32"] = {"error": str(e)}
+    try:
+        vblob, _ = weights.make_synthetic_vit("vit_b16", seed=1)
+        be = Backend("vit_b16", vblob, max_batch=64, temperature=1.5, conf_kind="entropy")
+        dt = timed(be, frames[:64], 10)
+        be.close()
+        out["vit_b16@64"] = {"config": "BASELINE configs[4] per-GPU share: ViT-B/16, 64 frames per call, entropy confidence",
+                             "frames_per_s": 64 / dt, "ms_per_call": dt * 1e3, "tflops": 64 * 2 * VIT_B16_GMAC / dt / 1e3}
+    except Exception as e:
+        out["vit_b16@64"] = {"error": str(e)}
+    return out
+
+
+def launch_command(gpus: int, argv, port: int | None = None):
+    """The child command `python bench.py --gpus N` runs when no torchrun environment is present."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -82,21 +187,35 @@ def main():
     ap.add_argument("--chunk-a", type=int, default=0)
     ap.add_argument("--chunk-b", type=int, default=0)
     ap.add_argument("--regroup-block", type=int, default=-1)
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="timed repeats of the CPU baseline")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs (single pass, ensemble, ViT)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def main():
+    args = parse_args()
+    # ---- rank layout; self-launch BEFORE anything initialises the GPU -------------------------
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+            env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+            sys.exit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     from failure_aware_vision_amd import Backend, classify_sharded, synth, weights
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -169,21 +288,30 @@ def main():
             total_ms = sum(v["ms"] for v in prof.values())
             tf = cv["flops"] / secs / 1e12 if secs > 0 else 0.0
             gbs = cv["bytes"] / secs / 1e9 if secs > 0 else 0.0
-            common = {"kernel": "fav::conv_igemm_kernel + fav::conv3x3_halo_kernel (every conv / fc launch of the timed steps)",
+            common = {"kernel": "fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel "
+                                "(every conv / fc launch of the timed steps)",
                       "launches": cv["launches"], "avg_launch_us": 1e3 * cv["ms"] / max(1, cv["launches"]),
                       "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None,
                       "timing": "HIP events recorded on the launch stream around every launch, inside the timed region"}
-            # The unfused layer-by-layer workload is HBM-bound overall (186 FLOP/B algorithmic vs
-            # 312 FLOP/B machine balance), so the binding roofline is HBM.
+            # Layer by layer the workload is HBM-bound overall (algorithmic FLOP/B below the machine
+            # balance of 312 FLOP/B), so the binding roofline is HBM.
             tr = pmc_traffic()
+            fresh = tr is not None and not tr.get("stale")
             out["roofline"] = dict(common, bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                                    frac=gbs / PEAK_HBM_GBS,
-                                   traffic=tr["bytes_per_launch"] if tr else None,   # HBM bytes per launch from the PMC passes
+                                   traffic=tr["bytes_per_launch"] if fresh else None,   # HBM bytes per launch from the PMC passes
                                    traffic_detail=tr,
                                    algorithmic_bytes_per_launch=cv["bytes"] / max(1, cv["launches"]))
             out["roofline_mfma"] = dict(common, bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                                         frac=tf / PEAK_BF16_TFLOPS, traffic=None)
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+    be.close()
+    if rank == 0:
+        if world == 1 and not args.no_extra:
+            try:
+                out["extra"] = secondary_configs(blob, args, torch, synth, weights, Backend)
+            except Exception as e:   # secondary lines are reported, never required
+                out["extra"] = {"error": str(e)}
         if args.cpu_frames > 0 and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             try:
                 out["cpu_baseline"] = cpu_baseline(blob, args, T, args.policy)
@@ -194,7 +322,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    be.close()
 
 
 if __name__ == "__main__":

@@ -39,6 +39,7 @@ class Backend:
         import torch
         self._torch = torch
         self._h = None
+        self._rules = None
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("failure_aware_vision_amd.Backend needs a gfx950 GPU (torch.cuda.is_available() is "
@@ -84,7 +85,7 @@ class Backend:
             self.load_weights(blob)
         self.mc = cfg.site_mask != 0 and round(cfg.dropout_p * 256) > 0
         self.T = cfg.n_samples if self.mc else max(1, cfg.n_members)
-        self._prev_status_provider = None
+        self._rules = None   # SignalAnalyzerHIP, created on the first analyze_frame
 
     # -- lifecycle ------------------------------------------------------------
     def load_weights(self, blob: bytes, member: int = 0):
@@ -92,7 +93,10 @@ class Backend:
         _lib.check(self.lib.fav_load_member_weights(self._h, int(member), buf, len(blob)), self._h)
 
     def reset(self):
-        """Scorer reset on mode switch (main.py:222,227,242,288).  The classifier is stateless."""
+        """Scorer reset on mode switch (main.py:222,227,242,288).  The classifier is stateless; the rule
+        scorer's previous-gray / frozen-run state is cleared like SignalAnalyzer.reset (signal_analyzer.py:37-39)."""
+        if self._rules is not None:
+            self._rules.reset()
 
     def close(self):
         if self._h is not None:
@@ -183,22 +187,45 @@ class Backend:
 
     # -- the reference seam ----------------------------------------------------------
     def analyze_frame(self, frame: np.ndarray, status_provider=None) -> dict:
-        """One uint8 HxWx3 frame -> the dict SignalAnalyzer.analyze_frame returns
-        (signal_analyzer.py:128-143): anomaly_score in [0,1] rounded to 6 places and a
-        vision_status string.  The classifier is an ML sensor only: the rule-based
-        status comes from ``status_provider(frame)`` when given, else VISION_OK
-        (ML influence is only active under VISION_OK, trust_engine.py:179,192)."""
-        status = status_provider(frame) if status_provider is not None else "VISION_OK"
+        """ONE call at the seam (main.py:160): a uint8 HxWx3 frame -> the dict SignalAnalyzer.analyze_frame returns
+        (signal_analyzer.py:128-143), carrying BOTH the rule-based ``vision_status`` of the reference's scorer and
+        the classifier-derived ``anomaly_score`` in [0,1] (rounded to 6 places), ready for
+        ``TrustEngine.update(vision_status, anomaly_score, dt)`` (main.py:168).
+
+        The frame is uploaded once; the fused signal-statistics kernel (signal.py, the reference's four pixel
+        metrics) and the classifier are queued on the same stream and the host synchronises once.  The
+        classifier is an ML sensor only (ML influence is active only under VISION_OK, trust_engine.py:179,192);
+        the rule metrics stay available under ``metrics['signal']``.  ``status_provider(frame) -> str`` replaces the
+        built-in rules when given.  On failure ``anomaly_score`` is None, which the engine tolerates
+        (trust_engine.py:101-103,193)."""
+        torch = self._torch
+        status, rule_metrics = "VISION_OK", None
         try:
-            labels, conf, fail, score = self.classify_detect(np.ascontiguousarray(frame)[None])
+            fr = np.ascontiguousarray(frame)
+            if status_provider is not None:
+                status = status_provider(frame)
+                labels, conf, fail, score = self.classify_detect(fr[None])
+                l0, c0, f0, s0 = int(labels[0]), float(conf[0]), bool(fail[0]), float(score[0])
+            else:
+                if self._rules is None:
+                    from .signal import SignalAnalyzerHIP
+                    self._rules = SignalAnalyzerHIP(self.device)
+                dev = torch.from_numpy(fr[None]).to(f"cuda:{self.device}")
+                stats_dev = self._rules.launch_stats(dev)
+                labels, conf, fail, score = self.classify_detect(dev)
+                packed = torch.stack([labels.to(torch.float32), conf, fail.to(torch.float32), score])   # [4, 1]
+                host = torch.cat([stats_dev, packed.view(torch.uint8).flatten()]).cpu().numpy()          # the one sync
+                nstat = stats_dev.numel()
+                rule = self._rules.score_stats(self._rules.parse_stats(host[:nstat].tobytes(), 1))[0]
+                status, rule_metrics = rule["vision_status"], rule
+                vals = host[nstat:].view(np.float32)
+                l0, c0, f0, s0 = int(vals[0]), float(vals[1]), bool(vals[2]), float(vals[3])
         except Exception:  # the seam's convention: no ML score available (trust_engine.py:101-103)
             return {"anomaly_score": None, "vision_status": status, "metrics": {}}
-        return {
-            "anomaly_score": round(float(score[0]), 6),
-            "vision_status": status,
-            "metrics": {"label": int(labels[0]), "confidence": round(float(conf[0]), 4), "fail": bool(fail[0]),
-                        "samples": self.T},
-        }
+        metrics = {"label": l0, "confidence": round(c0, 4), "fail": f0, "samples": self.T}
+        if rule_metrics is not None:
+            metrics["signal"] = dict(rule_metrics["metrics"], anomaly_score=rule_metrics["anomaly_score"])
+        return {"anomaly_score": round(s0, 6), "vision_status": status, "metrics": metrics}
 
 
 def anomaly_score_from_confidence(conf):

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,6 +126,7 @@ struct fav_handle {
     int T_eff = 1;                  // samples actually run
     int first_site = -1;
     void* host_stage = nullptr;     // for fav_classify_host
+    hipStream_t host_stream = nullptr;
     // ViT path (arch 2, 3): layers in blob order (kh == 0: a pair of fp32 vectors kept in w / b), fixed buffers
     bool vit = false;
     int vit_ntok = 0;
@@ -173,6 +175,15 @@ struct Prof {
     ~Prof() {
         if (idx >= 0) (void)hipEventRecord(h->ev_pool[idx].b, s);
     }
+};
+
+// Per-device "done once" flags: a process may hold handles on several devices (fav_config.device), and a
+// function attribute such as the dynamic-LDS limit is a property of (kernel, device).
+struct DeviceFlags {
+    std::atomic<unsigned long long> bits[2] = {};   // up to 128 device ordinals
+    static int current() { int d = 0; (void)hipGetDevice(&d); return (d < 0 || d >= 128) ? 0 : d; }
+    bool test_current() const { const int d = current(); return (bits[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1ull; }
+    void set_current() { const int d = current(); bits[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release); }
 };
 
 DropParams make_drop(const fav_dropout_desc* d) {
@@ -312,17 +323,17 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
         const int HBM = halo_cfg == 0 ? 128 : 256;
         const int wstages = d.Cin == 64 ? (halo_cfg == 0 ? 2 : 3) : (halo_cfg == 0 ? 2 : 4);   // K tiles of weights held in LDS
         const int patch_bytes = (int)((((long long)(HBM + 2 * d.W + 2) * d.Cin * 2) + 1023) / 1024 * 1024);
-        const int lds = patch_bytes + wstages * d.Cout * 128 + d.Cout * 4 + 16;
+        const int lds = patch_bytes + wstages * d.Cout * 128 + d.Cout * 5 + 16;
         if (lds <= 160 * 1024) {
             p.nk = 9 * d.Cin / 64;
             dim3 hgrid((unsigned)((p.M + HBM - 1) / HBM));
 #define FAV_HALO(KERNEL_)                                                                                            \
     do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
+        static DeviceFlags attr_set;   /* hipFuncSetAttribute applies to the CURRENT device only */                  \
+        if (!attr_set.test_current()) {                                                                              \
             if (hipFuncSetAttribute((const void*)KERNEL_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
                 return "conv: cannot reserve LDS for the staged 3x3 kernel";                                         \
-            attr_set = true;                                                                                         \
+            attr_set.set_current();                                                                                  \
         }                                                                                                            \
         hipLaunchKernelGGL(KERNEL_, hgrid, dim3(HBM * 2), lds, s, p, patch_bytes);                                   \
     } while (0)
@@ -456,12 +467,12 @@ const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, i
     if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
     const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
     const int lds = nkt * 16 * 128 + 64 * vstride + 8 * 16 * vstride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr_set;
+    if (!attr_set.test_current()) {
         if (hipFuncSetAttribute((const void*)attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return "attention: cannot reserve LDS";
-        attr_set = true;
+        attr_set.set_current();
     }
     const double flops = 4.0 * n * heads * (double)T * T * 64;
     Prof pr(h, s, FAV_K_CONV, flops, (double)n * T * D * 2 * 4);
@@ -857,6 +868,7 @@ void free_all(fav_handle* h) {
     for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
     if (h->logits) (void)hipFree(h->logits);
     if (h->host_stage) (void)hipFree(h->host_stage);
+    if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     for (void* q : {h->v_patches, h->v_emb, h->v_x, h->v_y, h->v_qkv, h->v_hid, h->v_cls}) if (q) (void)hipFree(q);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 }
@@ -1029,20 +1041,61 @@ void fav_destroy(fav_handle* h) {
 
 fav_status fav_load_weights(fav_handle* h, const void* blob, size_t size) { return fav_load_member_weights(h, 0, blob, size); }
 
-fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* blob, size_t size) {
-    if (!h) return FAV_ERR_INVALID_ARG;
-    if (member < 0 || member >= h->n_members) { h->err = fmt("fav_load_member_weights: member %d outside [0, %d)", member, h->n_members); return FAV_ERR_INVALID_ARG; }
-    if (!blob || size < 32) { h->err = "fav_load_weights: blob too small"; return FAV_ERR_BAD_BLOB; }
+// Structural validation of a FAVW v1 blob; needs no device and no handle.  Every offset is taken from the
+// (untrusted) file, so the range checks are written overflow-safe (off > size || bytes > size - off) and
+// the data must be aligned for its element type (pack_blob emits 64-byte aligned offsets).
+fav_status fav_check_blob(const void* blob, size_t size, char* err, size_t err_cap) {
+    auto fail = [&](const std::string& m) {
+        if (err && err_cap) { snprintf(err, err_cap, "%s", m.c_str()); }
+        return FAV_ERR_BAD_BLOB;
+    };
+    if (err && err_cap) err[0] = 0;
+    if (!blob || size < 32) return fail("blob too small");
     const uint8_t* p = (const uint8_t*)blob;
     uint32_t hdr[8];
     memcpy(hdr, p, 32);
-    if (hdr[0] != 0x57564146u || hdr[1] != 1u) { h->err = "fav_load_weights: not a FAVW v1 blob"; return FAV_ERR_BAD_BLOB; }
+    if (hdr[0] != 0x57564146u || hdr[1] != 1u) return fail("not a FAVW v1 blob");
+    const size_t nl = hdr[4];
+    if (nl == 0 || nl > 4096) return fail("implausible layer count");
+    if ((size - 32) / 48 < nl) return fail("truncated layer table");
+    const size_t data0 = 32 + 48 * nl;
+    auto in_range = [&](uint64_t off, uint64_t bytes, uint64_t align) {
+        return off >= data0 && off <= size && bytes <= size - off && off % align == 0;
+    };
+    for (size_t i = 0; i < nl; ++i) {
+        uint32_t t[8];
+        uint64_t off[2];
+        memcpy(t, p + 32 + 48 * i, 32);
+        memcpy(off, p + 32 + 48 * i + 32, 16);
+        const uint64_t cout = t[0], cin = t[1], kh = t[2], kw = t[3];
+        if (cout == 0 || cout > (1u << 24) || cin > (1u << 20) || kh > 64 || kw > 64) return fail(fmt("layer %zu: implausible shape", i));
+        if (kh == 0) {   // a pair of fp32 vectors
+            if (!in_range(off[0], cout * 4, 4) || !in_range(off[1], cout * 4, 4)) return fail(fmt("layer %zu data out of range", i));
+            continue;
+        }
+        if (kw == 0 || cin == 0) return fail(fmt("layer %zu: implausible shape", i));
+        const uint64_t k = kh * kw * cin;   // < 2^32
+        if (k > (1ull << 32) / cout) return fail(fmt("layer %zu: implausible shape", i));
+        if (!in_range(off[0], cout * k * 2, 2) || !in_range(off[1], cout * 4, 4)) return fail(fmt("layer %zu data out of range", i));
+    }
+    return FAV_OK;
+}
+
+fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* blob, size_t size) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    if (member < 0 || member >= h->n_members) { h->err = fmt("fav_load_member_weights: member %d outside [0, %d)", member, h->n_members); return FAV_ERR_INVALID_ARG; }
+    {
+        char msg[200];
+        if (fav_check_blob(blob, size, msg, sizeof msg) != FAV_OK) { h->err = std::string("fav_load_weights: ") + msg; return FAV_ERR_BAD_BLOB; }
+    }
+    const uint8_t* p = (const uint8_t*)blob;
+    uint32_t hdr[8];
+    memcpy(hdr, p, 32);
     if ((int)hdr[2] != h->cfg.arch || (int)hdr[3] != h->cfg.num_classes || hdr[4] != h->layers.size()) {
         h->err = fmt("fav_load_weights: blob is arch %u / %u classes / %u layers, handle expects %d / %d / %zu", hdr[2], hdr[3],
                      hdr[4], h->cfg.arch, h->cfg.num_classes, h->layers.size());
         return FAV_ERR_BAD_BLOB;
     }
-    if (size < 32 + 48 * (size_t)hdr[4]) { h->err = "fav_load_weights: truncated layer table"; return FAV_ERR_BAD_BLOB; }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     std::vector<uint16_t> wtmp;
     std::vector<float> btmp;
@@ -1059,7 +1112,7 @@ fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* bl
         }
         if (L.kh == 0) {   // a pair of fp32 vectors (LayerNorm gamma / beta, ViT position table)
             const size_t vb = (size_t)L.cout * 4;
-            if (off[0] + vb > size || off[1] + vb > size) { h->err = fmt("fav_load_weights: layer %zu data out of range", i); return FAV_ERR_BAD_BLOB; }
+            // (ranges and alignment already validated by fav_check_blob against these very table entries)
             L.w_m.resize(h->n_members, nullptr);
             L.b_m.resize(h->n_members, nullptr);
             if (!L.w_m[member]) HIP_TRY(h, hipMalloc((void**)&L.w_m[member], vb));
@@ -1070,7 +1123,7 @@ fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* bl
         }
         const size_t kreal = (size_t)L.kh * L.kw * L.cin;
         const size_t wbytes = (size_t)L.cout * kreal * 2, bbytes = (size_t)L.cout * 4;
-        if (off[0] + wbytes > size || off[1] + bbytes > size) { h->err = fmt("fav_load_weights: layer %zu data out of range", i); return FAV_ERR_BAD_BLOB; }
+        (void)wbytes;
         // device layout: [cout_pad][L.k] bf16, zero padded in both dimensions
         wtmp.assign((size_t)L.cout_pad * L.k, 0);
         const uint16_t* src = (const uint16_t*)(p + off[0]);
@@ -1167,7 +1220,12 @@ fav_status fav_classify_host(fav_handle* h, const void* images, int32_t n, int32
                              int32_t* labels, float* conf, uint8_t* fail, float* score) {
     if (!h) return FAV_ERR_INVALID_ARG;
     if (!images || !labels || !conf || n < 1 || n > h->cfg.max_batch) { h->err = "fav_classify_host: bad argument"; return FAV_ERR_INVALID_ARG; }
+    // validate everything that sizes the copy BEFORE touching the caller's buffer
+    if (layout != FAV_LAYOUT_NHWC_U8 && layout != FAV_LAYOUT_NHWC_F32) { h->err = "fav_classify_host: unknown layout"; return FAV_ERR_INVALID_ARG; }
+    if (!h->weights_loaded) { h->err = "fav_classify_host: no weights loaded"; return FAV_ERR_NO_WEIGHTS; }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->host_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
+    hipStream_t hs = h->host_stream;
     const size_t bpe = layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4;
     const size_t img_bytes = (size_t)h->cfg.max_batch * h->cfg.in_h * h->cfg.in_w * 3 * 4;
     const size_t res_off = (img_bytes + 255) / 256 * 256;
@@ -1177,14 +1235,15 @@ fav_status fav_classify_host(fav_handle* h, const void* images, int32_t n, int32
     float* dc = (float*)(dl + h->cfg.max_batch);
     float* ds = dc + h->cfg.max_batch;
     uint8_t* df = (uint8_t*)(ds + h->cfg.max_batch);
-    HIP_TRY(h, hipMemcpy(base, images, (size_t)n * h->cfg.in_h * h->cfg.in_w * 3 * bpe, hipMemcpyHostToDevice));
-    fav_status st = fav_classify_ex(h, base, n, layout, first_index, dl, dc, df, ds, nullptr);
+    // everything on the handle's own stream; only that stream is synchronised (not the device)
+    HIP_TRY(h, hipMemcpyAsync(base, images, (size_t)n * h->cfg.in_h * h->cfg.in_w * 3 * bpe, hipMemcpyHostToDevice, hs));
+    fav_status st = fav_classify_ex(h, base, n, layout, first_index, dl, dc, df, ds, hs);
     if (st != FAV_OK) return st;
-    HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(labels, dl, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(conf, dc, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (score) HIP_TRY(h, hipMemcpy(score, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (fail) HIP_TRY(h, hipMemcpy(fail, df, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpyAsync(labels, dl, (size_t)n * 4, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(h, hipMemcpyAsync(conf, dc, (size_t)n * 4, hipMemcpyDeviceToHost, hs));
+    if (score) HIP_TRY(h, hipMemcpyAsync(score, ds, (size_t)n * 4, hipMemcpyDeviceToHost, hs));
+    if (fail) HIP_TRY(h, hipMemcpyAsync(fail, df, (size_t)n, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(h, hipStreamSynchronize(hs));
     return FAV_OK;
 }
 

@@ -291,7 +291,7 @@ __device__ __forceinline__ int lds_swz(int row) {
 // waves per SIMD the LDS footprint allows (what __launch_bounds__ should ask for)
 constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
     const int stage = NS * (BM + BN) * BK * 2, out = 64 * (BN + 4) * 4;
-    const int lds = (stage > out ? stage : out) + BN * 4;
+    const int lds = (stage > out ? stage : out) + BN * 5;
     int blocks = 163840 / lds;
     if (blocks > 4) blocks = 4;
     if (BN >= 128 && blocks > 3) blocks = 3;  // 64 accumulators + the prefetched residual need > 128 VGPRs
@@ -314,7 +314,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     constexpr int OUT_BYTES = 64 * OUT_LD * 4;  // the epilogue stages 64 rows (one wave row) at a time
     constexpr int LDS_BYTES = (NS * STAGE_BYTES > OUT_BYTES) ? NS * STAGE_BYTES : OUT_BYTES;
     constexpr int AR = A_BYTES / 1024 / NWAVES, BR = B_BYTES / 1024 / NWAVES;  // LDS-DMA pieces per wave per tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BN * 4];  // + this tile's bias
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BN * 5];  // + this tile's bias, 16-channel chunks 20 floats apart
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -337,7 +337,10 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     // The tile's bias goes to LDS now: on gfx9 stores count in vmcnt like loads, so ANY global
     // load inside the epilogue would wait for every store issued before it (a full write
     // round trip per pass).  The epilogue therefore issues all its loads before its first store.
-    if (tid < BN) ((float*)(smem + LDS_BYTES))[tid] = p.bias[n0 + tid];
+    // Chunk c of 16 channels lives at float offset 20*c: the epilogue's lanes read 8 (BN = 128) or 16 (BN = 256)
+    // different chunks with one ds_read_b128, and at a stride of 16 floats chunks c and c+4 share their banks
+    // (2- and 4-way conflicts: the 13 % / 18 % LDS conflict cycles of profiles/r1e); 5*c mod 16 is distinct for c < 16.
+    if (tid < BN) ((float*)(smem + LDS_BYTES))[(tid >> 4) * 20 + (tid & 15)] = p.bias[n0 + tid];
 
     // ---- epilogue geometry, and the residual prefetch -------------------------------
     // A thread finishes 16 consecutive channels of one output pixel per pass.  The residual
@@ -350,7 +353,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     constexpr int NGROUPS = BM / 64;
     const int ec = tid % NCH, er = tid / NCH;
     const int n = n0 + ec * 16;
-    const float* bias_s = (const float*)(smem + LDS_BYTES) + ec * 16;
+    const float* bias_s = (const float*)(smem + LDS_BYTES) + ec * 20;
     constexpr bool RES_ALL = NGROUPS * NPASS * 2 <= 8;
     constexpr int RG = RES_ALL ? NGROUPS : 1;
     u32x4_t rres[RG][NPASS][2];
@@ -561,7 +564,10 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
 #pragma unroll
                 for (int b = 0; b < TM; ++b) {
                     const int ml = b * 16 + frow;  // row inside the 64-row group
-                    const int nl = wn * WTN + a * 16 + fq * 4;
+                    // BN = 256: a row is 16 chunks and the reading lanes of one ds_read_b128 group span chunks
+                    // {0-3, 12-15 | 4-11 of the next row}; chunks c and c+8 (>= 8: float4 slot ^ 2) must not share banks
+                    const int cw = (wn * WTN + a * 16) >> 4;
+                    const int nl = cw * 16 + ((fq ^ (BN == 256 ? ((cw >> 3) & 1) * 2 : 0)) << 2);
                     *(f32x4_t*)(outs + ml * OUT_LD + nl) = acc[a][b];
                 }
         }
@@ -586,7 +592,8 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const float4 t4 = *(const float4*)(outs + ml * OUT_LD + ec * 16 + 8 * g + 4 * q);
+                    const int gs = BN == 256 ? (g ^ ((ec >> 3) & 1)) : g;   // the staging swizzle (see the writes)
+                    const float4 t4 = *(const float4*)(outs + ml * OUT_LD + ec * 16 + 8 * gs + 4 * q);
                     const float4 bq = *(const float4*)(bias_s + 8 * g + 4 * q);
                     v[4 * q] = __fadd_rn(t4.x, bq.x); v[4 * q + 1] = __fadd_rn(t4.y, bq.y);
                     v[4 * q + 2] = __fadd_rn(t4.z, bq.z); v[4 * q + 3] = __fadd_rn(t4.w, bq.w);
@@ -678,10 +685,10 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
     constexpr int OUT_LD = BN + 4;
     static_assert(NKT % SUB == 0 && BR >= 1 && WAVES_M * WAVES_N == NWAVES, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-    // [patch | NS*SUB weight K tiles | bias (BN floats) | 16 zero bytes]; the fp32 staging of the epilogue overlays the patch
+    // [patch | NS*SUB weight K tiles | bias (16-channel chunks, 20 floats apart) | 16 zero bytes]; the fp32 staging of the epilogue overlays the patch
     unsigned char* const Bring = hsm + patch_bytes;
     float* const bias_s = (float*)(Bring + NS * SUB * B_BYTES);
-    const uint32_t zero_off = (uint32_t)(patch_bytes + NS * SUB * B_BYTES + BN * 4);
+    const uint32_t zero_off = (uint32_t)(patch_bytes + NS * SUB * B_BYTES + BN * 5);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
     }
     const int m0 = tile * BM;
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
-    if (tid < BN) bias_s[tid] = p.bias[tid];
+    if (tid < BN) bias_s[(tid >> 4) * 20 + (tid & 15)] = p.bias[tid];
     if (tid < 4) ((uint32_t*)(hsm + zero_off))[tid] = 0u;
 
     const uint32_t lds_base =
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t4 = *(const float4*)(outs + ml * OUT_LD + n + 4 * q);
-                const float4 bq = *(const float4*)(bias_s + n + 4 * q);
+                const float4 bq = *(const float4*)(bias_s + ec * 20 + 4 * q);
                 float v0 = __fadd_rn(t4.x, bq.x), v1 = __fadd_rn(t4.y, bq.y), v2 = __fadd_rn(t4.z, bq.z), v3 = __fadd_rn(t4.w, bq.w);
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 o[2 * q] = pack_bf16x2(v0, v1);

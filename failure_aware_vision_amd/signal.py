@@ -90,8 +90,9 @@ class SignalAnalyzerHIP:
         self._frame_count = 0
         self._consecutive_frozen = 0
 
-    def stats(self, frames):
-        """frames: uint8 [n, H, W, 3] (numpy or CUDA tensor) -> list of FavSignalStats (host)."""
+    def launch_stats(self, frames):
+        """Queue the fused statistics pass for uint8 [n, H, W, 3] frames (numpy or CUDA tensor) on the current
+        stream; returns the device byte tensor holding n fav_signal_stats records (no host sync)."""
         torch = self._torch
         if isinstance(frames, np.ndarray):
             frames = torch.from_numpy(np.ascontiguousarray(frames)).to(f"cuda:{self.device}")
@@ -108,17 +109,29 @@ class SignalAnalyzerHIP:
         _lib.check(self.lib.fav_op_signal_stats(frames.data_ptr(), n, H, W, prev.data_ptr() if prev is not None else None,
                                                 last.data_ptr(), out.data_ptr(), stream))
         self._prev_gray = last
-        host = out.cpu().numpy().tobytes()
-        return [FavSignalStats.from_buffer_copy(host, i * C.sizeof(FavSignalStats)) for i in range(n)]
+        return out
 
-    def analyze_frames(self, frames) -> list:
+    @staticmethod
+    def parse_stats(host_bytes: bytes, n: int) -> list:
+        return [FavSignalStats.from_buffer_copy(host_bytes, i * C.sizeof(FavSignalStats)) for i in range(n)]
+
+    def stats(self, frames):
+        """frames: uint8 [n, H, W, 3] (numpy or CUDA tensor) -> list of FavSignalStats (host)."""
+        n = int(frames.shape[0])
+        return self.parse_stats(self.launch_stats(frames).cpu().numpy().tobytes(), n)
+
+    def score_stats(self, stats) -> list:
+        """The scalar scoring + status rules over a list of FavSignalStats (advances the frozen-run state)."""
         res = []
-        for st in self.stats(frames):
+        for st in stats:
             self._frame_count += 1
             r, self._consecutive_frozen = score_frame(st.lap_var, st.mean, st.mean_diff if st.has_prev else None,
                                                       float(st.entropy), self._consecutive_frozen)
             res.append(r)
         return res
+
+    def analyze_frames(self, frames) -> list:
+        return self.score_stats(self.stats(frames))
 
     def analyze_frame(self, frame: np.ndarray) -> dict:
         return self.analyze_frames(np.ascontiguousarray(frame)[None])[0]

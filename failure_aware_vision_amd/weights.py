@@ -296,3 +296,109 @@ def pack_blob(arch: int, num_classes: int, specs, folded) -> bytes:
     for o, b in chunks:
         buf[o:o + len(b)] = b
     return bytes(buf)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Trained checkpoints: torch state_dict -> FAVW blob
+# ---------------------------------------------------------------------------------------------------------
+def _np(t):
+    return np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float64)
+
+
+def _fold_conv_bn(sd, conv, bn, eps):
+    """OIHW conv weight (+ optional conv bias) followed by eval-mode BatchNorm -> (bf16 bits [O,kh,kw,I], fp32 bias[O]).
+    The BN scale is multiplied into the weights BEFORE their bf16 rounding, the shift goes to the fp32 bias."""
+    w = _np(sd[conv + ".weight"])
+    gamma, beta = _np(sd[bn + ".weight"]), _np(sd[bn + ".bias"])
+    mean, var = _np(sd[bn + ".running_mean"]), _np(sd[bn + ".running_var"])
+    scale = gamma / np.sqrt(var + eps)
+    cb = _np(sd[conv + ".bias"]) if conv + ".bias" in sd else 0.0
+    wq = _bf16((w * scale[:, None, None, None]).transpose(0, 2, 3, 1).astype(np.float32))
+    return wq, (beta + (cb - mean) * scale).astype(np.float32)
+
+
+def _linear(sd, name, shape_ohwi=None):
+    w = _np(sd[name + ".weight"])
+    if w.ndim == 4:                                   # a convolution used as a linear map (ViT patch embedding)
+        w = w.transpose(0, 2, 3, 1)
+    else:
+        w = w.reshape(w.shape[0], 1, 1, -1)
+    b = _np(sd[name + ".bias"]) if name + ".bias" in sd else np.zeros(w.shape[0])
+    return _bf16(w.astype(np.float32)), b.astype(np.float32)
+
+
+def from_state_dict(arch, sd, num_classes: int | None = None, bn_eps: float = 1e-5, mean=DEFAULT_MEAN, std=DEFAULT_STD):
+    """Converts a trained torch ``state_dict`` into the FAVW blob ``fav_load_weights`` takes -> (blob, info).
+
+    * ``resnet50`` / ``resnet18_cifar``: torchvision naming (``conv1``, ``bn1``, ``layerL.B.convK`` / ``bnK``,
+      ``layerL.B.downsample.0`` / ``.1``, ``fc``).  Every BatchNorm is folded in eval mode: scale into the bf16
+      weights (before rounding), shift into the fp32 bias; the blob's layer order is stem, per block conv1, conv2,
+      (conv3), (downsample), then fc.  ResNet-50 must be v1.5 (stride on the 3x3), as torchvision's is.
+    * ``vit_b16`` / ``vit_tiny``: timm naming (``patch_embed.proj``, ``cls_token``, ``pos_embed``, ``blocks.i.norm1``,
+      ``attn.qkv``, ``attn.proj``, ``norm2``, ``mlp.fc1``, ``mlp.fc2``, ``norm``, ``head``); qkv rows are
+      Q | K | V with head h in rows 64h..64h+63 of each, the class token is added into row 0 of the position table.
+      The device MLP uses the tanh form of GELU.
+    """
+    aid = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
+    specs, folded = [], []
+    if aid in VIT_CFG:
+        cfg = VIT_CFG[aid]
+        D, depth, P = cfg["dim"], cfg["depth"], cfg["patch"]
+        pe = _np(sd["patch_embed.proj.weight"])
+        if pe.shape != (D, 3, P, P):
+            raise ValueError(f"patch_embed.proj.weight is {pe.shape}, expected {(D, 3, P, P)}")
+        specs.append(dict(cout=D, cin=3, kh=P, kw=P, stride=P, pad=0)); folded.append(_linear(sd, "patch_embed.proj"))
+        pos = _np(sd["pos_embed"]).reshape(-1, D).copy()
+        pos[0] += _np(sd["cls_token"]).reshape(D)
+        specs.append(dict(cout=pos.size, cin=0, kh=0, kw=0, stride=0, pad=0))
+        folded.append((pos.reshape(-1).astype(np.float32), np.zeros(pos.size, np.float32)))
+
+        def vec(name):
+            specs.append(dict(cout=D, cin=0, kh=0, kw=0, stride=0, pad=0))
+            folded.append((_np(sd[name + ".weight"]).astype(np.float32), _np(sd[name + ".bias"]).astype(np.float32)))
+
+        def lin(name):
+            wq, b = _linear(sd, name)
+            specs.append(dict(cout=wq.shape[0], cin=wq.shape[3], kh=1, kw=1, stride=1, pad=0)); folded.append((wq, b))
+
+        for i in range(depth):
+            p = f"blocks.{i}."
+            vec(p + "norm1"); lin(p + "attn.qkv"); lin(p + "attn.proj"); vec(p + "norm2"); lin(p + "mlp.fc1"); lin(p + "mlp.fc2")
+        vec("norm"); lin("head")
+        ncls = folded[-1][0].shape[0]
+        ntok = pos.shape[0]
+        hw = int(round((ntok - 1) ** 0.5)) * P
+        info_extra = dict(in_hw=(hw, hw), n_tokens=ntok)
+    else:
+        a = _ARCH[aid]
+        ncls = int(_np(sd["fc.weight"]).shape[0])
+        nmain = 3 if a["block"] == "bottleneck" else 2
+        for sp in layer_specs(aid, ncls):
+            if sp["role"] == "stem":
+                wq, b = _fold_conv_bn(sd, "conv1", "bn1", bn_eps)
+            elif sp["role"] == "fc":
+                wq, b = _linear(sd, "fc")
+            else:
+                blk, stage = sp["block"], 0
+                while blk >= a["depths"][stage]:
+                    blk -= a["depths"][stage]; stage += 1
+                p = f"layer{stage + 1}.{blk}."
+                if sp["role"] == "down":
+                    wq, b = _fold_conv_bn(sd, p + "downsample.0", p + "downsample.1", bn_eps)
+                else:
+                    k = sum(1 for q in specs if q.get("_p") == p) + 1     # conv index inside the block, blob order
+                    if k > nmain:
+                        raise ValueError("layer order mismatch")
+                    wq, b = _fold_conv_bn(sd, f"{p}conv{k}", f"{p}bn{k}", bn_eps)
+                    sp = dict(sp, _p=p)
+            if wq.shape != (sp["cout"], sp["kh"], sp["kw"], sp["cin"]):
+                raise ValueError(f"{sp['role']} of block {sp['block']}: checkpoint tensor is {wq.shape}, the architecture expects "
+                                 f"{(sp['cout'], sp['kh'], sp['kw'], sp['cin'])} (ResNet-50 must be v1.5)")
+            specs.append(sp); folded.append((wq, b))
+        info_extra = {}
+    if num_classes is not None and int(num_classes) != ncls:
+        raise ValueError(f"checkpoint has {ncls} classes, {num_classes} requested")
+    blob = pack_blob(aid, ncls, specs, folded)
+    info = dict(arch=arch, num_classes=ncls, n_layers=len(specs), sha256=hashlib.sha256(blob).hexdigest(), mean=tuple(mean),
+                std=tuple(std), source="state_dict", **info_extra)
+    return blob, info

@@ -93,6 +93,10 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out);
 fav_status fav_load_weights(fav_handle* h, const void* blob_host, size_t size);   /* member 0 */
 fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* blob_host, size_t size);
 void fav_destroy(fav_handle* h);
+/* Structural validation of a checkpoint blob (magic, version, layer table, every data range and its
+ * alignment), without a device or a handle; fav_load_*_weights runs it first.  err (may be NULL)
+ * receives a message.  The blob is file-supplied, hence untrusted. */
+fav_status fav_check_blob(const void* blob_host, size_t size, char* err, size_t err_cap);
 const char* fav_last_error(const fav_handle* h); /* h may be NULL: error of the last failed fav_create */
 int32_t fav_abi_version(void);
 

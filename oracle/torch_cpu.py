@@ -42,6 +42,17 @@ class TorchNet:
         self.fc_w = torch.from_numpy(fc.w.reshape(fc.cout, -1).copy())
         self.fc_b = torch.from_numpy(fc.b)
         self.nb = len(self.blocks)
+        # Dropout masks are INPUTS of the workload (hard part 3): with `mask_cache` set to a
+        # dict, every generated keep mask is stored under (t, site) and reused by later calls with the same
+        # arguments, so bench.py's cpu_baseline can generate them in its warm-up call, outside the timed region.
+        self.mask_cache = None
+
+    def _cached(self, key, make):
+        if self.mask_cache is None:
+            return make()
+        if key not in self.mask_cache:
+            self.mask_cache[key] = make()
+        return self.mask_cache[key]
 
     @staticmethod
     def _conv(x, L, res=None, relu=True, keep=None, scale=1.0):
@@ -81,13 +92,22 @@ class TorchNet:
         return F.linear(_bf16(y), self.fc_w, self.fc_b)
 
     @staticmethod
-    def _keep_nchw(seed, t, site, img_ids, shape_nchw, thr):
+    def _make_keep_nchw(seed, t, site, img_ids, shape_nchw, thr):
         b, c, h, w = shape_nchw
         k = O.dropout_keep(seed, t, site, img_ids, h * w * c, thr).reshape(b, h, w, c)
         return torch.from_numpy(np.ascontiguousarray(k.transpose(0, 3, 1, 2)))
 
+    def _keep_nchw(self, seed, t, site, img_ids, shape_nchw, thr):
+        return self._cached((t, site), lambda: self._make_keep_nchw(seed, t, site, img_ids, shape_nchw, thr))
+
+    def _keep_vec(self, seed, t, site, img_ids, n, thr):
+        return self._cached((t, site), lambda: torch.from_numpy(O.dropout_keep(seed, t, site, img_ids, n, thr)))
+
     @torch.no_grad()
-    def forward_logits(self, xn_nhwc: np.ndarray, img_ids=None, n_samples=1, site_mask=0, p=0.0, seed=0):
+    def forward_logits(self, xn_nhwc: np.ndarray, img_ids=None, n_samples=1, site_mask=0, p=0.0, seed=0,
+                       stack_samples=False):
+        """stack_samples: run the T suffix passes as ONE batch of T*B frames (same arithmetic per frame, so the
+        same logits; larger convolutions are what a many-core host runs best - the cpu_baseline setting)."""
         x = torch.from_numpy(np.ascontiguousarray(xn_nhwc.transpose(0, 3, 1, 2))).contiguous(
             memory_format=torch.channels_last)
         b = x.shape[0]
@@ -114,8 +134,26 @@ class TorchNet:
                 act = self.block(i, act, keep, scale)
             keep = None
             if site_mask >> self.nb & 1:
-                keep = torch.from_numpy(O.dropout_keep(seed, t, self.nb, img_ids, act.shape[1], thr))
+                keep = self._keep_vec(seed, t, self.nb, img_ids, act.shape[1], thr)
             return self.pool_fc(act, keep, scale)
+
+        def run_from_stacked(stage, act_t):
+            """act_t: list over t of [B,C,H,W]; all samples advance together as one [T*B] batch."""
+            T = len(act_t)
+            act = torch.cat(act_t, dim=0).contiguous(memory_format=torch.channels_last)
+            for i in range(stage, self.nb):
+                keep = None
+                if site_mask >> i & 1:
+                    shp = out_shape(i, act_t[0])
+                    keep = self._cached(("stacked", i), lambda: torch.cat(
+                        [self._make_keep_nchw(seed, t, i, img_ids, shp, thr) for t in range(T)], dim=0))
+                act = self.block(i, act, keep, scale)
+                act_t = [act[:b]]   # only its shape is used
+            keep = None
+            if site_mask >> self.nb & 1:
+                keep = self._cached(("stacked", self.nb), lambda: torch.cat(
+                    [torch.from_numpy(O.dropout_keep(seed, t, self.nb, img_ids, act.shape[1], thr)) for t in range(T)], dim=0))
+            return self.pool_fc(act, keep, scale).reshape(T, b, -1)
 
         act = self.stem(x)
         if first > self.nb:
@@ -132,9 +170,14 @@ class TorchNet:
                     acc = acc + act[:, :, i, j]
             pooled = _bf16(acc * float(np.float32(1.0 / (h_ * w_))))
         outs = []
+        if stack_samples and first < self.nb:
+            keep0 = self._cached(("stacked", first), lambda: torch.cat(
+                [self._make_keep_nchw(seed, t, first, img_ids, tuple(act.shape), thr) for t in range(n_samples)], dim=0))
+            ent = _bf16(torch.where(keep0, act.repeat(n_samples, 1, 1, 1) * scale, zero))
+            return run_from_stacked(npre, list(ent.split(b, dim=0))).numpy()
         for t in range(n_samples):
             if first == self.nb:
-                keep = torch.from_numpy(O.dropout_keep(seed, t, first, img_ids, pooled.shape[1], thr))
+                keep = self._keep_vec(seed, t, first, img_ids, pooled.shape[1], thr)
                 outs.append(F.linear(_bf16(torch.where(keep, pooled * scale, zero)), self.fc_w, self.fc_b))
             else:
                 keep = self._keep_nchw(seed, t, first, img_ids, tuple(act.shape), thr)
@@ -142,10 +185,11 @@ class TorchNet:
         return torch.stack(outs).numpy()
 
 
-def classify(model: O.Model, images: np.ndarray, cfg: O.ClassifyConfig, img_ids=None, return_logits=False, net=None):
+def classify(model: O.Model, images: np.ndarray, cfg: O.ClassifyConfig, img_ids=None, return_logits=False, net=None,
+             stack_samples=False):
     net = net or TorchNet(model)
     xn = O.normalize_input(images, cfg.mean, O.inv_std32(cfg.std))
-    lg = net.forward_logits(xn, img_ids, cfg.n_samples, cfg.site_mask, cfg.p, cfg.seed)
+    lg = net.forward_logits(xn, img_ids, cfg.n_samples, cfg.site_mask, cfg.p, cfg.seed, stack_samples=stack_samples)
     z = torch.from_numpy(lg) * float(np.float32(1.0 / cfg.temperature))
     pbar = torch.softmax(z, dim=-1).mean(dim=0).numpy()
     labels = pbar.argmax(axis=-1).astype(np.int32)

@@ -22,3 +22,13 @@ def r18_blob():
 def r50_blob():
     from failure_aware_vision_amd import weights
     return weights.make_synthetic("resnet50", seed=1)
+
+
+ENSEMBLE_SEEDS = (1, 2, 3, 4, 5)
+
+
+@pytest.fixture(scope="session")
+def r50_members():
+    """BASELINE configs[3]: five independently seeded ResNet-50 checkpoints -> [(blob, info)] (member 0 = r50_blob's)."""
+    from failure_aware_vision_amd import weights
+    return [weights.make_synthetic("resnet50", seed=s) for s in ENSEMBLE_SEEDS]

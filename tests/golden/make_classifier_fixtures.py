@@ -7,6 +7,7 @@ the fixtures hold only expected outputs.
   python tests/golden/make_classifier_fixtures.py mfma_mc # 16 frames, T=30 all_blocks, production bf16-MFMA model
   python tests/golden/make_classifier_fixtures.py mfma_1k # 1,000 frames, single pass, production bf16-MFMA model
   python tests/golden/make_classifier_fixtures.py vit     # ViT-B/16, 16 corrupted frames, production bf16-MFMA model
+  python tests/golden/make_classifier_fixtures.py ens5    # BASELINE configs[3]: 5 ResNet-50 members (seeds 1..5), 16 frames, production model
 """
 import os, sys, time, zlib
 import numpy as np
@@ -55,6 +56,30 @@ if what == "vit":
                         blob_sha256=info["sha256"],
                         meta="vit_b16 seed1; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; single pass, entropy "
                              "confidence at temperature 1.5; production mode (v_mfma_f32_16x16x32_bf16 model)")
+elif what == "ens5":
+    # BASELINE configs[3]: five independently seeded ResNet-50 members, 224x224, severity-3 frames, single pass per
+    # member, head = mean over members of softmax.  Per member and frame: CRC-32 of the 1000 fp32 logits.
+    n, seeds = 16, (1, 2, 3, 4, 5)
+    cfg = O.ClassifyConfig(exact="mfma")
+    x = frames(0, n)
+    lgs, shas = [], []
+    for sd in seeds:
+        t0 = time.time()
+        mb, mi = weights.make_synthetic("resnet50", seed=sd)
+        shas.append(mi["sha256"])
+        mm = O.parse_blob(mb)
+        parts = [O.classify(mm, x[s:s + 4], cfg, return_logits=True)[2] for s in range(0, n, 4)]
+        lgs.append(np.concatenate(parts, axis=1)[0])          # [n, 1000]
+        print("ens5 member seed", sd, time.time() - t0, flush=True)
+    lg = np.stack(lgs)                                          # [5, n, 1000]: the head sees members as samples
+    l, c, pb = O.confidence_head(lg)
+    crc = np.array([[zlib.crc32(np.ascontiguousarray(lg[m, i]).tobytes()) for i in range(n)] for m in range(len(seeds))], np.uint32)
+    np.savez_compressed(os.path.join(HERE, "r50_ens5_mfma_16.npz"), labels=l.astype(np.int16), conf=c, gap=gap_of(pb),
+                        member_logit_crc32=crc, member_blob_sha256=np.array(shas), member_seeds=np.array(seeds),
+                        member_labels=lg.argmax(axis=2).astype(np.int16), blob_sha256=shas[0],
+                        meta="5 x resnet50 seeds 1..5; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; single pass per member, "
+                             "mean of member softmax; production mode (v_mfma_f32_16x16x32_bf16 model); member_logit_crc32[m][i] = "
+                             "zlib.crc32 of member m's 1000 fp32 logits of frame i")
 elif what == "mc":
     n, T = 64, 30
     cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact=True)

@@ -142,13 +142,13 @@ def test_resnet50_every_layer_teacher_forced(r50_blob):
 
 
 def test_full_size_properties(r50_blob):
-    """BASELINE headline shape (ResNet-50, 224x224, batch 256, MC-Dropout): properties
+    """BASELINE headline shape (ResNet-50, 224x224, batch 256, MC-Dropout T = 30): properties
     that need no oracle run.  (a) determinism; (b) shard invariance: two half batches
     with first_image_index give bit-identical results (what the 8-GPU path relies on,
     SURVEY.md §8e); (c) chunking invariance: pass sizes change the schedule, not the
     result; (d) a frame's result does not depend on its neighbours."""
     blob, _ = r50_blob
-    n, T = 256, 4
+    n, T = 256, 30        # the headline shape exactly: 256 frames x T = 30, all_blocks
     frames = torch.from_numpy(synth.synthetic_frames_u8(n, 224, 224, seed=21)).cuda()
     kw = dict(n_samples=T, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
     be = Backend("resnet50", blob, max_batch=n, **kw)
@@ -201,6 +201,40 @@ def test_error_behaviour(r18_blob):
     frame = synth.synthetic_frame_u8(32, 32, 1, 0)
     out = be.analyze_frame(frame)
     assert set(out) == {"anomaly_score", "vision_status", "metrics"}
-    assert 0.0 <= out["anomaly_score"] <= 1.0 and out["vision_status"] == "VISION_OK"
+    assert 0.0 <= out["anomaly_score"] <= 1.0 and out["vision_status"].startswith("VISION_")
     assert abs(out["anomaly_score"] - (1 - out["metrics"]["confidence"])) < 1e-3
+    assert be.analyze_frame(frame, status_provider=lambda f: "VISION_FROZEN")["vision_status"] == "VISION_FROZEN"
+    bad = be.analyze_frame(np.zeros((16, 16, 3), np.uint8))      # wrong size: the seam's "no ML score" convention
+    assert bad["anomaly_score"] is None and bad["metrics"] == {}
     be.close()
+
+
+def test_one_call_scorer_at_the_seam(r50_blob):
+    """main.py:160-168 with the drop-in: ONE Backend.analyze_frame call per 240x320 frame returns the rule status of
+    the reference's scorer (checked against its CPU restatement) AND the classifier's anomaly score, in the
+    reference's dict shape (signal_analyzer.py:128-143); the result drives TrustEngine.update."""
+    from failure_aware_vision_amd.trust import TrustEngine
+    from oracle.signal_oracle import SignalOracle
+    from test_gpu_signal import stream_of_frames
+    blob, _ = r50_blob
+    frames = stream_of_frames()
+    be = Backend("resnet50", blob, in_hw=(240, 320), max_batch=1, n_samples=4, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    ref_be = Backend("resnet50", blob, in_hw=(240, 320), max_batch=1, n_samples=4, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    orc, eng, seen = SignalOracle(), TrustEngine(), set()
+    for i, fr in enumerate(frames):
+        out = be.analyze_frame(fr)
+        ref = orc.analyze_frame(fr)
+        assert set(out) == {"anomaly_score", "vision_status", "metrics"}
+        assert out["vision_status"] == ref["vision_status"], i
+        sig = out["metrics"]["signal"]
+        assert abs(sig["anomaly_score"] - ref["anomaly_score"]) <= 2e-6
+        assert sig["raw"]["mean_brightness"] == ref["metrics"]["raw"]["mean_brightness"]
+        labels, conf, fail, score = ref_be.classify_detect(fr[None])          # the classifier alone, same frame
+        assert out["metrics"]["label"] == int(labels[0]) and out["anomaly_score"] == round(float(score[0]), 6)
+        state = eng.update(out["vision_status"], out["anomaly_score"], 1 / 30)
+        seen.add(out["vision_status"])
+    assert seen == {"VISION_OK", "VISION_FROZEN", "VISION_BLANK", "VISION_CORRUPTED"}
+    assert 0.0 <= state["reliability"] <= 1.0
+    be.reset()
+    assert be.analyze_frame(frames[0])["metrics"]["signal"]["raw"]["frame_diff"] == 10.0   # reset cleared the previous frame
+    be.close(); ref_be.close()

@@ -172,3 +172,115 @@ def test_plain_c_caller_matches_python_backend(lib, tmp_path):
     be.close()
     assert [int(x[0]) for x in rows] == labels.cpu().tolist()
     assert np.allclose([float(x[1]) for x in rows], conf.cpu().numpy(), rtol=0, atol=1e-7)
+
+
+# ---- checkpoint blob validation (file-supplied, hence hostile) ----------------------------------------------------
+def _check(lib, blob: bytes):
+    err = C.create_string_buffer(200)
+    st = lib.fav_check_blob(blob, len(blob), err, 200)
+    return st, err.value.decode()
+
+
+def test_check_blob_accepts_real_checkpoints_and_rejects_hostile_tables(lib, r18_blob):
+    import struct
+    from failure_aware_vision_amd import weights
+    blob, _ = r18_blob
+    assert _check(lib, blob) == (0, "")
+    vblob, _ = weights.make_synthetic_vit("vit_tiny", seed=3)
+    assert _check(lib, vblob)[0] == 0
+    BAD = 2   # FAV_ERR_BAD_BLOB
+    assert _check(lib, blob[:16])[0] == BAD and _check(lib, b"")[0] == BAD
+    assert _check(lib, blob[:32 + 48 * 3])[0] == BAD                       # truncated layer table
+    assert _check(lib, blob[:len(blob) - 64])[0] == BAD                     # truncated data
+    nl = struct.unpack_from("<I", blob, 16)[0]
+
+    def patched(layer, field_off, fmt, value):
+        b = bytearray(blob)
+        struct.pack_into(fmt, b, 32 + 48 * layer + field_off, value)
+        return bytes(b)
+
+    for layer in (0, nl // 2, nl - 1):
+        w_off, b_off = struct.unpack_from("<2Q", blob, 32 + 48 * layer + 32)
+        # an offset near 2^64 must not wrap past the range check (off + bytes overflow)
+        for off in (2 ** 64 - 8, 2 ** 64 - 64, 2 ** 63, len(blob), len(blob) - 2):
+            st, msg = _check(lib, patched(layer, 32, "<Q", off))
+            assert st == BAD and "out of range" in msg, (layer, off, msg)
+            assert _check(lib, patched(layer, 40, "<Q", off))[0] == BAD
+        assert _check(lib, patched(layer, 32, "<Q", w_off + 1))[0] == BAD   # bf16 data must be 2-byte aligned
+        assert _check(lib, patched(layer, 40, "<Q", b_off + 2))[0] == BAD   # fp32 data must be 4-byte aligned
+        assert _check(lib, patched(layer, 32, "<Q", 8))[0] == BAD           # data inside the header
+        assert _check(lib, patched(layer, 0, "<I", 0))[0] == BAD            # cout = 0
+        assert _check(lib, patched(layer, 0, "<I", 0xFFFFFFFF))[0] == BAD   # cout * k overflows
+    b = bytearray(blob)
+    struct.pack_into("<I", b, 16, 0x7FFFFFFF)                               # absurd layer count
+    assert _check(lib, bytes(b))[0] == BAD
+    b = bytearray(blob); b[0] ^= 0xFF
+    assert _check(lib, bytes(b))[0] == BAD
+
+
+# ---- bench.py launch logic (no GPU, no torch import in the parent) -------------------------------------------------
+def test_bench_self_launch_command_and_world_size_check():
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], port=29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    # a launcher that started a different number of ranks than --gpus is an error, not silently ignored
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    # the parent of a self-launch must not have imported torch (it would initialise HIP before the exec of the children)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert not re.search(r"^(import|from)\s+torch", src, re.M)                      # no module-level torch import
+    body = src[src.index("def main()"):]
+    assert body.index("subprocess.call(launch_command") < body.index("import torch")   # spawn first, torch later
+
+
+def test_pmc_traffic_is_tied_to_the_kernel_sources():
+    import json
+    import bench
+    tr = bench.pmc_traffic()
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    if d.get("kernel_source_sha256") == bench.kernel_source_sha():
+        assert tr["bytes_per_launch"] == d["conv_bytes_per_launch"]
+    else:
+        assert tr.get("stale") is True and "bytes_per_launch" not in tr
+
+
+_NCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from failure_aware_vision_amd import Backend, classify_sharded, shard_range, synth, weights
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+blob, _ = weights.make_synthetic("resnet18_cifar", seed=1)
+kw = dict(n_samples=3, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+n = 11
+frames = synth.synthetic_frames_u8(n, 32, 32, seed=5)
+be = Backend("resnet18_cifar", blob, device=rank, max_batch=n, **kw)
+s, e = shard_range(n, rank, world)
+labels, conf = classify_sharded(be.classify, torch.from_numpy(frames[s:e]).cuda(), n, rank, world)
+full_l, full_c = be.classify(torch.from_numpy(frames).cuda())          # the 1-GPU result, on this rank's GPU
+assert torch.equal(labels, full_l) and torch.equal(conf, full_c), (labels, full_l)   # bit for bit
+dist.barrier(); dist.destroy_process_group(); be.close()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_classify_nccl_world2(tmp_path):
+    """The N>1 path over RCCL on two real GPUs: gathered result == 1-GPU result bit for bit.
+    Skipped on a one-GPU box (two ranks cannot share one device under RCCL)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    script = tmp_path / "worker.py"
+    script.write_text(_NCCL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -1,0 +1,85 @@
+"""weights.from_state_dict: a trained torch checkpoint (torchvision ResNet / timm ViT naming) -> FAVW blob, with
+BatchNorm folded.  A random network in eval mode with non-trivial running statistics is converted and run through
+the CPU oracle; its logits must agree with the torch module's own fp32 forward up to the bf16 rounding of
+weights and layer-boundary activations (a wrong fold, transpose or layer order gives O(1) errors)."""
+import numpy as np
+import pytest
+import torch
+
+from failure_aware_vision_amd import synth, weights
+from oracle import fav_oracle as O
+from torch_models import ResNet, VisionTransformer
+
+
+def randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=g)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
+            m.running_mean.data = 0.3 * torch.randn(m.running_mean.shape, generator=g)
+            m.running_var.data = 0.5 + torch.rand(m.running_var.shape, generator=g)
+
+
+def he_init(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.Conv2d):
+            fan = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+            m.weight.data = torch.randn(m.weight.shape, generator=g) * (1.0 / fan) ** 0.5
+
+
+def rel_rms(a, b):
+    return float(np.sqrt(((a - b) ** 2).mean()) / b.std())
+
+
+@pytest.mark.parametrize("arch,hw,ncls", [("resnet18_cifar", 32, 10), ("resnet50", 64, 40)])
+def test_resnet_state_dict_folds_to_the_same_function(arch, hw, ncls):
+    torch.manual_seed(3)
+    net = ResNet(arch, ncls).eval()
+    he_init(net, 5); randomise_bn(net, 7)
+    blob, info = weights.from_state_dict(arch, net.state_dict())
+    assert info["num_classes"] == ncls
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(4, hw, hw, seed=9)
+    cfg = O.ClassifyConfig()
+    labels, conf, lg, _ = O.classify(model, frames, cfg, return_logits=True)
+    xn = (frames.astype(np.float32) / 255.0 - np.asarray(cfg.mean, np.float32)) / np.asarray(cfg.std, np.float32)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(xn.transpose(0, 3, 1, 2).copy())).numpy()
+    assert lg.shape == (1, 4, ncls)
+    assert rel_rms(lg[0], ref) < 0.03, rel_rms(lg[0], ref)
+    # the same specs / order as the synthetic generator, so the device accepts it (structural check, no GPU needed)
+    sblob, _ = weights.make_synthetic(arch, seed=1, num_classes=ncls)
+    assert len(blob) == len(sblob) and blob[:32] == sblob[:32]
+    n = int.from_bytes(blob[16:20], "little")
+    assert all(blob[32 + 48 * i:32 + 48 * i + 24] == sblob[32 + 48 * i:32 + 48 * i + 24] for i in range(n))
+    from failure_aware_vision_amd import _lib
+    import os
+    if os.path.exists(_lib.LIB_PATH):
+        assert _lib.load().fav_check_blob(blob, len(blob), None, 0) == 0
+
+
+def test_resnet50_v1_checkpoints_are_rejected():
+    net = ResNet("resnet50", 10)
+    sd = dict(net.state_dict())
+    sd["layer1.0.conv2.weight"] = torch.zeros(64, 64, 1, 1)        # not a 3x3: wrong architecture
+    with pytest.raises(ValueError):
+        weights.from_state_dict("resnet50", sd)
+
+
+def test_vit_state_dict_converts_to_the_same_function():
+    torch.manual_seed(11)
+    net = VisionTransformer(num_classes=50).eval()
+    blob, info = weights.from_state_dict("vit_tiny", net.state_dict())
+    assert info["n_tokens"] == 17 and info["in_hw"] == (64, 64)
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(3, 64, 64, seed=2)
+    cfg = O.ClassifyConfig()
+    _, _, lg, _ = O.classify(model, frames, cfg, return_logits=True)
+    xn = (frames.astype(np.float32) / 255.0 - np.asarray(cfg.mean, np.float32)) / np.asarray(cfg.std, np.float32)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(xn.transpose(0, 3, 1, 2).copy())).numpy()
+    assert rel_rms(lg[0], ref) < 0.03, rel_rms(lg[0], ref)
+    sblob, _ = weights.make_synthetic_vit("vit_tiny", seed=3, num_classes=50)
+    assert len(blob) == len(sblob)
