@@ -73,6 +73,27 @@ def pmc_traffic():
         return None
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a share of the host, and oversubscribing it with one thread per host core is several times slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -93,6 +114,8 @@ def cpu_baseline(blob, args, T, policy):
     from oracle import fav_oracle as O
     from oracle import torch_cpu as TC
     n = args.cpu_frames
+    threads = args.cpu_threads if args.cpu_threads > 0 else min(torch.get_num_threads(), effective_cpus())
+    torch.set_num_threads(threads)
     frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(n, 224, 224, seed=21), 3, seed=3)
     model = O.parse_blob(blob)
     net = TC.TorchNet(model)
@@ -113,6 +136,7 @@ def cpu_baseline(blob, args, T, policy):
     return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "batch": n, "repeats": len(times), "seconds": times, "warmup_seconds": warm,
             "gflops": n * gf / dt, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "usable_cpus": effective_cpus(),
             "sample": f"{n} frames x T={T} ({policy}) = {n * T} suffix passes in one stacked batch, oracle/torch_cpu.py "
                       f"fp32 MKL-DNN on {torch.get_num_threads()} threads; 1 warm-up call (also generates the Philox "
                       f"masks: inputs, not timed) + {len(times)} timed calls, median {dt:.2f} s"}
@@ -189,6 +213,7 @@ def parse_args(argv=None):
     ap.add_argument("--regroup-block", type=int, default=-1)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-repeats", type=int, default=3, help="timed repeats of the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = the CPUs this job may use)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs (single pass, ensemble, ViT)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args(argv)

@@ -48,6 +48,13 @@ class FavConvDesc(C.Structure):
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("math_mode", C.c_int32), ("drop", FavDropoutDesc)]
 
 
+class FavTailDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("wb", C.c_void_p), ("bias_b", C.c_void_p), ("wc", C.c_void_p), ("bias_c", C.c_void_p),
+                ("res", C.c_void_p), ("y", C.c_void_p), ("wa", C.c_void_p), ("bias_a", C.c_void_p), ("t1n", C.c_void_p),
+                ("n_frames", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cmid", C.c_int32), ("Nred", C.c_int32),
+                ("drop", FavDropoutDesc)]
+
+
 class FavProfile(C.Structure):
     _fields_ = [("ms", C.c_double * K_COUNT), ("flops", C.c_double * K_COUNT), ("bytes", C.c_double * K_COUNT),
                 ("launches", C.c_int64 * K_COUNT)]
@@ -79,6 +86,7 @@ _SIGNATURES = {
     "fav_get_profile": (C.c_int, [C.c_void_p, C.POINTER(FavProfile), C.c_int32]),
     "fav_get_op_profile": (C.c_int, [C.c_void_p, C.POINTER(FavOpProfile), C.c_int32, C.POINTER(C.c_int32)]),
     "fav_op_conv2d": (C.c_int, [C.POINTER(FavConvDesc), C.c_void_p]),
+    "fav_op_bottleneck_tail": (C.c_int, [C.POINTER(FavTailDesc), C.c_void_p]),
     "fav_op_stem_im2col": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.c_void_p, C.c_void_p]),

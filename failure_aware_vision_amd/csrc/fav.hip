@@ -70,13 +70,16 @@ struct Layer {  // one convolution / fc
     std::vector<float*> b_m;
 };
 
-enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT };
+enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT, OP_TAIL };
 enum BufId { B_INPUT = -1, B_PHASE_IN = -2, B_PHASE_OUT = -3, B_NONE = -4, B_A1 = 5 };  // 0..4 rotating
 
 struct Op {
     OpKind kind;
-    int layer = -1;          // conv layer index
+    int layer = -1;          // conv layer index (OP_TAIL: the 3x3, or -1 when the tail starts at the expanding 1x1)
+    int layer_c = -1, layer_a = -1;   // OP_TAIL: the expanding 1x1 and the NEXT block's reducing 1x1 (-1: none)
     int in = B_NONE, out = B_NONE, res = B_NONE;
+    int out2 = B_NONE;       // OP_TAIL: the next block's conv1 output
+    int Co2 = 0;
     int H = 0, W = 0, C = 0;           // input dims per frame
     int Ho = 0, Wo = 0, Co = 0;        // output dims per frame
     int relu = 0, out_f32 = 0;
@@ -379,6 +382,74 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     return nullptr;
 }
 
+
+// ---- bottleneck tail (conv_b 3x3 -> conv_c 1x1 + residual + dropout -> next block's conv_a 1x1), one launch ----
+struct TailGeom { int patch_bytes, rega_bytes, lds_bytes; };
+// LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS> (must match the kernel's own layout)
+bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
+    if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
+    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2;
+    const int patch = has3x3 ? (int)((((long long)(128 + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
+    int rega = std::max(std::max(patch, 64 * 68 * 4 + 128 * 128), 128 * rowb);
+    if (nred == 128) rega = std::max(rega, 64 * 132 * 4);
+    rega = (rega + 1023) / 1024 * 1024;
+    const int ring = std::max(has3x3 ? ns * cmid * 128 : 0, nred * 128);
+    g->patch_bytes = patch;
+    g->rega_bytes = rega;
+    g->lds_bytes = rega + ring + 64 * rowb + (cmid + 4 * cmid + nred) * 5 + 16;
+    return g->lds_bytes <= 160 * 1024;
+}
+
+bool tail_enabled() {
+    static const int on = [] { const char* e = getenv("FAV_FUSE"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
+const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
+    const bool has3x3 = d.wb != nullptr;
+    const int nred = d.wa ? d.Nred : 0;
+    TailGeom g;
+    if (!tail_geometry(d.Cmid, nred, has3x3, d.W, &g)) return "bottleneck tail: unsupported shape";
+    const long long M = (long long)d.n_frames * d.H * d.W;
+    if (M <= 0 || M > 0x7fffffffLL) return "bottleneck tail: row count out of range";
+    TailParams p;
+    p.t1 = (const uint16_t*)d.x; p.wb = (const uint16_t*)d.wb; p.bias_b = d.bias_b;
+    p.wc = (const uint16_t*)d.wc; p.bias_c = d.bias_c; p.res = (const uint16_t*)d.res; p.y = (uint16_t*)d.y;
+    p.wa = (const uint16_t*)d.wa; p.bias_a = d.bias_a; p.t1n = (uint16_t*)d.t1n;
+    p.H = d.H; p.W = d.W; p.HW = d.H * d.W; p.M = (int)M;
+    p.rega_bytes = g.rega_bytes;
+    p.drop = make_drop(&d.drop);
+    p.div_hw = fastdiv_make((uint32_t)p.HW);
+    p.div_w = fastdiv_make((uint32_t)d.W);
+    if (p.drop.site >= 0 && (p.drop.v0 < 0 || p.drop.v0 + d.n_frames > 0x7fffffffLL)) return "bottleneck tail: virtual frame index out of range";
+    const int cmid = d.Cmid, cout = 4 * cmid;
+    const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
+    const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
+    Prof pr(h, s, FAV_K_CONV, flops, bytes);
+    dim3 grid((unsigned)((M + 127) / 128));
+#define FAV_TAIL(CMID_, NRED_, H3_, NS_)                                                                              \
+    do {                                                                                                              \
+        static DeviceFlags attr_set;                                                                                  \
+        if (!attr_set.test_current()) {                                                                               \
+            if (hipFuncSetAttribute((const void*)bottleneck_tail_kernel<CMID_, NRED_, H3_, NS_>,                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)            \
+                return "bottleneck tail: cannot reserve LDS";                                                         \
+            attr_set.set_current();                                                                                   \
+        }                                                                                                             \
+        hipLaunchKernelGGL((bottleneck_tail_kernel<CMID_, NRED_, H3_, NS_>), grid, dim3(256), g.lds_bytes, s, p, g.patch_bytes); \
+        return nullptr;                                                                                               \
+    } while (0)
+    if (cmid == 64) {
+        if (has3x3) { if (nred == 0) FAV_TAIL(64, 0, true, 3); if (nred == 64) FAV_TAIL(64, 64, true, 3); if (nred == 128) FAV_TAIL(64, 128, true, 3); }
+        else { if (nred == 0) FAV_TAIL(64, 0, false, 3); if (nred == 64) FAV_TAIL(64, 64, false, 3); if (nred == 128) FAV_TAIL(64, 128, false, 3); }
+    } else {
+        if (has3x3) { if (nred == 0) FAV_TAIL(128, 0, true, 2); if (nred == 128) FAV_TAIL(128, 128, true, 2); }
+        else { if (nred == 0) FAV_TAIL(128, 0, false, 2); if (nred == 128) FAV_TAIL(128, 128, false, 2); }
+    }
+#undef FAV_TAIL
+    return "bottleneck tail: unsupported shape";
+}
+
 // One work item per thread whenever the grid allows (grid-stride loops only catch the rest): on gfx9
 // stores count in vmcnt, so a second iteration's loads would wait for the first iteration's stores.
 unsigned grid_for(long long work_items) {
@@ -543,13 +614,26 @@ fav_status build_graph(fav_handle* h) {
     std::vector<int> block_last_op;
     const int exp = A.bottleneck ? 4 : 1;
     int inpl = 64, bidx = 0;
+    // phase boundaries in block units (known before the ops exist; the fused tails must not straddle them)
+    const int nblocks_total = A.depths[0] + A.depths[1] + A.depths[2] + A.depths[3];
+    int mc_first_site = -1;
+    {
+        const uint32_t thr0 = (uint32_t)std::lround((double)c.dropout_p * 256.0);
+        if (c.site_mask != 0 && thr0 > 0)
+            for (int sb = 0; sb <= nblocks_total; ++sb)
+                if (c.site_mask >> sb & 1) { mc_first_site = sb; break; }
+    }
+    int regroup_blk = c.regroup_block;
+    if (regroup_blk < 0) regroup_blk = A.depths[0] + A.depths[1];
+    regroup_blk = std::min(regroup_blk, nblocks_total);
+    int pre_t1 = -1;   // rotating buffer already holding the coming block's conv1 output
     for (int st = 0; st < 4; ++st) {
         for (int bi = 0; bi < A.depths[st]; ++bi, ++bidx) {
             const int pl = A.planes[st];
             const int s = (bi == 0 && st > 0) ? 2 : 1;
             const bool ds = (bi == 0) && (s != 1 || inpl != pl * exp);
             const int xin = cur;
-            int t1 = other({xin}), t2 = other({xin, t1});
+            int t1 = pre_t1 >= 0 ? pre_t1 : other({xin}), t2 = other({xin, t1});
             auto conv_op = [&](int layer, int in, int out, int res, int relu, int Hi, int Wi) {
                 const Layer& L = h->layers[layer];
                 Op o; o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.res = res; o.relu = relu;
@@ -562,17 +646,47 @@ fav_status build_graph(fav_handle* h) {
             int Hn, Wn;
             if (A.bottleneck) {
                 int l1 = add_layer(pl, inpl, 1, 1, 1, 0), l2 = add_layer(pl, pl, 3, 3, s, 1), l3 = add_layer(pl * 4, pl, 1, 1, 1, 0);
-                conv_op(l1, xin, t1, B_NONE, 1, H, W);
-                Op o2 = conv_op(l2, t1, t2, B_NONE, 1, H, W);
-                Hn = o2.Ho; Wn = o2.Wo;
-                int idn = xin;
+                if (pre_t1 < 0) conv_op(l1, xin, t1, B_NONE, 1, H, W);   // else: written by the previous block's fused tail
+                pre_t1 = -1;
+                Hn = conv_out(H, 3, s, 1); Wn = conv_out(W, 3, s, 1);
                 int ld = -1;
                 if (ds) ld = add_layer(pl * exp, inpl, 1, 1, s, 0);
+                // Fused tail (bottleneck_tail_kernel): conv2 (when 3x3/1) + conv3 (+ the NEXT block's conv1 unless a
+                // phase boundary or the end of the network lies between the two blocks).  Production math mode only.
+                const bool last_block = (st == 3 && bi + 1 == A.depths[3]);
+                const bool boundary_after = last_block || (mc_first_site == bidx) || (bidx + 1 == regroup_blk);
+                const int next_pl = (bi + 1 < A.depths[st]) ? pl : (st < 3 ? A.planes[st + 1] : 0);
+                int nred = boundary_after ? 0 : next_pl;
+                TailGeom tg;
+                const bool tail_3x3 = (s == 1);
+                bool fuse = tail_enabled() && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128);
+                if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {
+                    nred = 0;
+                    fuse = tail_geometry(pl, 0, tail_3x3, Wn, &tg);
+                }
+                int t2v = t1;
+                if (!(fuse && tail_3x3)) {                          // the 3x3 as its own launch
+                    conv_op(l2, t1, t2, B_NONE, 1, H, W);
+                    t2v = t2;
+                }
+                int idn = xin;
                 // blob order is conv1, conv2, conv3, downsample; launch order: downsample before conv3
                 if (ds) { idn = other({xin, t1, t2}); conv_op(ld, xin, idn, B_NONE, 0, H, W); }
-                int yout = ds ? other({xin, t1, t2, idn}) : t1;  // t1 is dead after conv2
-                conv_op(l3, t2, yout, idn, 1, Hn, Wn);
-                cur = yout;
+                if (fuse) {
+                    const int yout = other({xin, t1, t2v, idn});    // t2 is free when the 3x3 is fused, xin when it is not the residual
+                    Op o; o.kind = OP_TAIL; o.layer = tail_3x3 ? l2 : -1; o.layer_c = l3;
+                    o.layer_a = nred > 0 ? (int)h->layers.size() : -1;      // the next add_layer() is the next block's conv1
+                    o.in = t2v; o.res = idn; o.out = yout; o.relu = 1;
+                    o.H = Hn; o.W = Wn; o.C = pl; o.Ho = Hn; o.Wo = Wn; o.Co = pl * 4; o.Co2 = nred;
+                    o.in_elems = (long long)Hn * Wn * pl; o.out_elems = (long long)Hn * Wn * pl * 4;
+                    if (nred > 0) { o.out2 = other({t2v, idn, yout}); pre_t1 = o.out2; }
+                    h->ops.push_back(o);
+                    cur = yout;
+                } else {
+                    int yout = ds ? other({xin, t1, t2, idn}) : t1;  // t1 is dead after conv2
+                    conv_op(l3, t2, yout, idn, 1, Hn, Wn);
+                    cur = yout;
+                }
             } else {
                 int l1 = add_layer(pl, inpl, 3, 3, s, 1), l2 = add_layer(pl, pl, 3, 3, 1, 1);
                 Op o1 = conv_op(l1, xin, t1, B_NONE, 1, H, W);
@@ -675,7 +789,7 @@ fav_status build_graph(fav_handle* h) {
                     Op& o = h->ops[k];
                     if (o.in == src) o.in = B_PHASE_IN;
                     if (o.res == src) o.res = B_PHASE_IN;
-                    if (o.out == src) break;
+                    if (o.out == src || o.out2 == src) break;
                 }
             }
         }
@@ -828,6 +942,19 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                     d.drop = dd;
                     const int ldy = o.out_f32 ? L.cout_pad : L.cout;
                     if (const char* e = launch_conv(h, d, L.cout_pad, ldy, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
+                    break;
+                }
+                case OP_TAIL: {
+                    const Layer& Lc = h->layers[o.layer_c];
+                    fav_tail_desc d;
+                    memset(&d, 0, sizeof d);
+                    d.x = buf(o.in, false, o);
+                    if (o.layer >= 0) { d.wb = h->layers[o.layer].w; d.bias_b = h->layers[o.layer].b; }
+                    d.wc = Lc.w; d.bias_c = Lc.b; d.res = buf(o.res, false, o); d.y = buf(o.out, true, o);
+                    if (o.layer_a >= 0) { d.wa = h->layers[o.layer_a].w; d.bias_a = h->layers[o.layer_a].b; d.t1n = buf(o.out2, true, o); }
+                    d.n_frames = cn; d.H = o.H; d.W = o.W; d.Cmid = o.C; d.Nred = o.Co2;
+                    d.drop = dd;
+                    if (const char* e = launch_tail(h, d, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
                     break;
                 }
                 case OP_MAXPOOL:
@@ -1273,6 +1400,7 @@ fav_status fav_set_profiling(fav_handle* h, int32_t enable) {
         r.H = o.H; r.W = o.W; r.Cin = o.C; r.Ho = o.Ho; r.Wo = o.Wo; r.Cout = o.Co;
         r.kh = r.kw = r.stride = 0;
         if (o.layer >= 0) { const Layer& L = h->layers[o.layer]; r.kh = L.kh; r.kw = L.kw; r.stride = L.stride; }
+        if (o.kind == OP_TAIL) { r.reserved = o.Co2; if (o.layer < 0) { r.kh = r.kw = r.stride = 1; } }   // reserved: channels of the fused next-block conv1
     }
     return FAV_OK;
 }
@@ -1312,6 +1440,12 @@ fav_status fav_op_conv2d(const fav_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->bias || !d->y) return op_done("fav_op_conv2d: null pointer");
     if (d->Cout % 64 != 0) return op_done("fav_op_conv2d: Cout must be a multiple of 64");
     return op_done(launch_conv(nullptr, *d, d->Cout, d->Cout, (hipStream_t)stream));
+}
+
+fav_status fav_op_bottleneck_tail(const fav_tail_desc* d, void* stream) {
+    if (!d || !d->x || !d->wc || !d->bias_c || !d->res || !d->y) return op_done("fav_op_bottleneck_tail: null pointer");
+    if ((d->wb && !d->bias_b) || (d->wa && (!d->bias_a || !d->t1n))) return op_done("fav_op_bottleneck_tail: null pointer");
+    return op_done(launch_tail(nullptr, *d, (hipStream_t)stream));
 }
 
 fav_status fav_op_stem_im2col(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W, int32_t kh, int32_t kw,

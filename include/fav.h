@@ -139,7 +139,7 @@ typedef struct fav_profile {
 } fav_profile;
 /* One row per op of the static schedule (valid after fav_get_profile). */
 typedef struct fav_op_profile {
-    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout */
+    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout, 5 fused bottleneck tail */
     int32_t H, W, Cin, Ho, Wo, Cout, kh, kw, stride;
     int32_t reserved;
     double ms, flops, bytes;
@@ -172,6 +172,24 @@ typedef struct fav_conv_desc {
     fav_dropout_desc drop;
 } fav_conv_desc;
 fav_status fav_op_conv2d(const fav_conv_desc* d, void* hip_stream);
+
+/* Bottleneck tail (one launch): conv_b 3x3/1/1 Cmid->Cmid + ReLU (skipped when wb == NULL: x is then conv_c's
+ * input), conv_c 1x1 Cmid->4*Cmid + bias + residual + ReLU + dropout site -> y, and the NEXT block's conv_a
+ * 1x1 4*Cmid->Nred + ReLU -> t1n (skipped when wa == NULL).  Same arithmetic, k order and rounding points as the
+ * three fav_op_conv2d launches it replaces (bit-identical results); production math mode only.
+ * Cmid in {64, 128}; Nred in {0, Cmid, 128}. */
+typedef struct fav_tail_desc {
+    const void* x;                          /* [n][H][W][Cmid] bf16 */
+    const void* wb; const float* bias_b;    /* [Cmid][3][3][Cmid] bf16, [Cmid] */
+    const void* wc; const float* bias_c;    /* [4*Cmid][Cmid] bf16, [4*Cmid] */
+    const void* res;                        /* [n][H][W][4*Cmid] bf16 */
+    void* y;                                /* [n][H][W][4*Cmid] bf16 */
+    const void* wa; const float* bias_a;    /* [Nred][4*Cmid] bf16, [Nred] */
+    void* t1n;                              /* [n][H][W][Nred] bf16 */
+    int32_t n_frames, H, W, Cmid, Nred;
+    fav_dropout_desc drop;
+} fav_tail_desc;
+fav_status fav_op_bottleneck_tail(const fav_tail_desc* d, void* hip_stream);
 /* frames (u8 or fp32 NHWC3) -> normalised bf16 im2col matrix [n*Ho*Wo][kpad] */
 fav_status fav_op_stem_im2col(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W,
                               int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t kpad,

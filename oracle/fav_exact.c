@@ -334,7 +334,8 @@ void fav_layernorm_rows(const float* x, const float* gamma, const float* beta, f
 
 /* Attention softmax over rows of Tk scores (already scaled): the device holds, per query, keys
  * kt*16 + 4*fq + r in lane group fq (0..3); each group sums exp() of its keys in ascending
- * order, groups combine as (s0 + s1) + (s2 + s3).  p = e / sum. */
+ * order, groups combine as (s0 + s1) + (s2 + s3).  p = e * (1 / sum): ONE correctly rounded reciprocal per row
+ * and a multiplication per element (the device spends a VALU division only once per query). */
 void fav_attn_softmax_rows(const float* s, float* p, long rows, int Tk) {
 #pragma omp parallel for
     for (long q = 0; q < rows; ++q) {
@@ -348,6 +349,7 @@ void fav_attn_softmax_rows(const float* s, float* p, long rows, int Tk) {
             part[(k >> 2) & 3] = part[(k >> 2) & 3] + e;
         }
         const float sum = (part[0] + part[1]) + (part[2] + part[3]);
-        for (int k = 0; k < Tk; ++k) p[q * Tk + k] = p[q * Tk + k] / sum;
+        const float inv = 1.0f / sum;
+        for (int k = 0; k < Tk; ++k) p[q * Tk + k] = p[q * Tk + k] * inv;
     }
 }

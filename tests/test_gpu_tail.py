@@ -1,0 +1,102 @@
+"""bottleneck_tail_kernel (conv_b 3x3 -> conv_c 1x1 + residual + dropout -> the next block's conv_a 1x1 in one
+launch) against (a) the three separate fav_op_conv2d launches it replaces and (b) the CPU oracle with the bit-exact
+model of v_mfma_f32_16x16x32_bf16: every output element bit-identical - same k order, same rounding points, same
+Philox draws.  Shapes cover both channel widths, every fused combination the executor builds, ragged last tiles,
+frames smaller than a tile and non-square frames."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from failure_aware_vision_amd import _lib  # noqa: E402
+from oracle import fav_oracle as O  # noqa: E402
+from test_gpu_ops import dev_bf16, drop_desc, host_f32, run_conv  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def run_tail(lib, x, wb, bb, wc, bc, res, wa, ba, drop=None):
+    n, H, W, cmid = x.shape
+    cout = wc.shape[0]
+    nred = wa.shape[0] if wa is not None else 0
+    keep = [dev_bf16(x), dev_bf16(wc), torch.from_numpy(bc).cuda(), dev_bf16(res)]
+    y = torch.zeros((n, H, W, cout), dtype=torch.bfloat16, device="cuda")
+    t1n = torch.zeros((n, H, W, max(nred, 1)), dtype=torch.bfloat16, device="cuda")
+    wbd = dev_bf16(wb) if wb is not None else None
+    bbd = torch.from_numpy(bb).cuda() if wb is not None else None
+    wad = dev_bf16(wa) if wa is not None else None
+    bad = torch.from_numpy(ba).cuda() if wa is not None else None
+    d = _lib.FavTailDesc(keep[0].data_ptr(), wbd.data_ptr() if wbd is not None else None,
+                         bbd.data_ptr() if bbd is not None else None, keep[1].data_ptr(), keep[2].data_ptr(),
+                         keep[3].data_ptr(), y.data_ptr(), wad.data_ptr() if wad is not None else None,
+                         bad.data_ptr() if bad is not None else None, t1n.data_ptr() if wad is not None else None,
+                         n, H, W, cmid, nred, drop or drop_desc())
+    _lib.check(lib.fav_op_bottleneck_tail(C.byref(d), None))
+    torch.cuda.synchronize()
+    return host_f32(y), (host_f32(t1n) if wa is not None else None)
+
+
+CASES = [
+    # cmid, nred, has3x3, H, W, n
+    (64, 64, True, 56, 56, 2),      # layer 1 inner boundary; M = 6272 = 49 tiles
+    (64, 128, True, 56, 56, 1),     # layer 1 -> layer 2 (the next block reduces to 128)
+    (64, 0, True, 20, 12, 3),       # no next block; ragged last tile (M = 720)
+    (64, 64, True, 7, 9, 37),       # frames much smaller than a tile; M = 2331 (ragged)
+    (64, 64, True, 60, 80, 1),      # the 240x320 seam at layer 1 (H != W)
+    (128, 128, True, 28, 28, 3),    # layer 2 inner boundary
+    (128, 0, True, 28, 28, 2),      # last block of the high-resolution group
+    (128, 128, False, 28, 28, 3),   # the stride-2 block: its 3x3 stays a separate launch
+    (64, 64, False, 14, 10, 5),
+    (128, 128, True, 9, 11, 7),
+]
+
+
+@pytest.mark.parametrize("cmid,nred,has3x3,H,W,n", CASES)
+@pytest.mark.parametrize("with_drop", [False, True])
+def test_tail_bitwise_vs_separate_launches_and_oracle(lib, cmid, nred, has3x3, H, W, n, with_drop):
+    rng = np.random.default_rng(cmid * 31 + nred * 7 + H * W + n + int(has3x3))
+    cout = 4 * cmid
+    x = O.bf16_round(np.maximum(rng.standard_normal((n, H, W, cmid)) * np.exp2(rng.integers(-2, 3, (n, H, W, cmid))), -0.2).astype(np.float32))
+    wb = O.bf16_round((rng.standard_normal((cmid, 3, 3, cmid)) * np.sqrt(2.0 / (9 * cmid))).astype(np.float32)) if has3x3 else None
+    bb = (rng.standard_normal(cmid) * 0.2).astype(np.float32) if has3x3 else None
+    wc = O.bf16_round((rng.standard_normal((cout, 1, 1, cmid)) * np.sqrt(1.0 / cmid)).astype(np.float32))
+    bc = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    res = O.bf16_round(np.maximum(rng.standard_normal((n, H, W, cout)), 0).astype(np.float32))
+    wa = O.bf16_round((rng.standard_normal((nred, 1, 1, cout)) * np.sqrt(2.0 / cout)).astype(np.float32)) if nred else None
+    ba = (rng.standard_normal(nred) * 0.2).astype(np.float32) if nred else None
+    thr = 26
+    dd = drop_desc(site=5, thr=thr, scale=float(O.dropout_scale(thr)), seed=0x1234567ABC, v0=3, n_img=n + 1, first=40) if with_drop else None
+    # (a) the separate launches
+    t2 = run_conv(lib, x, wb, bb, None, 1, 1, relu=1) if has3x3 else x
+    y_ref = run_conv(lib, t2, wc, bc, res, 1, 0, relu=1, drop=dd)
+    t1n_ref = run_conv(lib, y_ref, wa, ba, None, 1, 0, relu=1) if nred else None
+    y, t1n = run_tail(lib, x, wb, bb, wc, bc, res, wa, ba, drop=dd)
+    assert np.array_equal(y, y_ref), f"Y: {np.mean(y != y_ref):.5f} of elements differ from the separate launches"
+    if nred:
+        assert np.array_equal(t1n, t1n_ref), f"t1': {np.mean(t1n != t1n_ref):.5f} of elements differ"
+    # (b) the oracle (MFMA model), small cases only
+    if n * H * W <= 8000:
+        keep = None
+        if with_drop:
+            # virtual frame v = v0 + i: sample t = v // n_img, frame (v % n_img) + first
+            v = 3 + np.arange(n)
+            t, img = v // (n + 1), v % (n + 1) + 40
+            keep = np.stack([O.dropout_keep(0x1234567ABC, int(tt), 5, np.array([ii]), H * W * cout, thr)[0] for tt, ii in zip(t, img)])
+        o2 = O.epilogue(O.conv_acc_exact(x, wb, 3, 3, 1, 1, mode="mfma"), bb) if has3x3 else x
+        oy = O.epilogue(O.conv_acc_exact(o2, wc, 1, 1, 1, 0, mode="mfma"), bc, res=res, relu=True, keep=keep, scale=O.dropout_scale(thr))
+        assert np.array_equal(y, oy), f"Y vs oracle: {np.mean(y != oy):.5f} differ"
+        if nred:
+            assert np.array_equal(t1n, O.epilogue(O.conv_acc_exact(oy, wa, 1, 1, 1, 0, mode="mfma"), ba))
+
+
+def test_tail_rejects_unsupported_shapes(lib):
+    x = torch.zeros((1, 8, 8, 96), dtype=torch.bfloat16, device="cuda")
+    d = _lib.FavTailDesc(x.data_ptr(), None, None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, None, None,
+                         1, 8, 8, 96, 0, drop_desc())
+    assert lib.fav_op_bottleneck_tail(C.byref(d), None) == 1      # FAV_ERR_INVALID_ARG, nothing launched

@@ -36,7 +36,7 @@ def conv_sum(sub, counter):
     tot, n = 0.0, 0
     if f:
         for row in csv.DictReader(open(f)):
-            if ("conv_igemm_kernel" in row["Kernel_Name"] or "conv3x3_halo_kernel" in row["Kernel_Name"]) and row["Counter_Name"] == counter:
+            if any(k in row["Kernel_Name"] for k in ("conv_igemm_kernel", "conv3x3_halo_kernel", "bottleneck_tail_kernel")) and row["Counter_Name"] == counter:
                 tot += float(row["Counter_Value"]); n += 1
     return tot, n
 fs, fn = conv_sum("pmc_fetch", "FETCH_SIZE")
@@ -45,9 +45,12 @@ if fn and wn:
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2
     fetch = fs * 1024.0 * 2.0 / fn
     write = ws * 1024.0 / wn
-    d = {"conv_fetch_bytes_per_launch": fetch, "conv_write_bytes_per_launch": write,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    d = {"kernel_source_sha256": bench.kernel_source_sha(),   # the sources these counters were measured on
+         "conv_fetch_bytes_per_launch": fetch, "conv_write_bytes_per_launch": write,
          "conv_bytes_per_launch": fetch + write, "launches_profiled": fn,
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1`, "
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-extra --no-profile`, "
                    "FETCH_SIZE x2 (gfx950 correction), " + os.path.basename(out.rstrip('/'))}
     json.dump(d, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("pmc_traffic", d)
