@@ -384,19 +384,32 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 
 
 // ---- bottleneck tail (conv_b 3x3 -> conv_c 1x1 + residual + dropout -> next block's conv_a 1x1), one launch ----
-struct TailGeom { int patch_bytes, rega_bytes, lds_bytes; };
-// LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS> (must match the kernel's own layout)
+struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2; };
+// Waves per block (pixels per block = 32 * waves).  64 mid channels: 4 waves (128 pixels, two blocks per CU) unless
+// FAV_TAIL_NW64=8; 128 mid channels: 8 waves (256 pixels, one block per CU).
+inline int tail_nw(int cmid) {
+    static const int nw64 = [] { const char* e = getenv("FAV_TAIL_NW64"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    return cmid == 64 ? nw64 : 8;
+}
+// LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
-    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2;
-    const int patch = has3x3 ? (int)((((long long)(128 + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
-    int rega = std::max(std::max(patch, 64 * 68 * 4 + 128 * 128), 128 * rowb);
-    if (nred == 128) rega = std::max(rega, 64 * 132 * 4);
+    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2, nw = tail_nw(cmid), bm = 32 * nw;
+    const int patch = has3x3 ? (int)((((long long)(bm + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
+    int rega = std::max(std::max(patch, bm * 128), bm * rowb);        // patch | T2 tile | Y chunk
     rega = (rega + 1023) / 1024 * 1024;
-    const int ring = std::max(has3x3 ? ns * cmid * 128 : 0, nred * 128);
+    const int tail = (cmid + 4 * cmid + nred) * 5 + 16;
+    // Wc double-buffered when two blocks still fit a CU (4-wave blocks) / the block fits at all (8-wave blocks)
+    const int ring = has3x3 ? ns * cmid * 128 : 0;
+    const int budget = nw == 4 ? 80 * 1024 : 160 * 1024;
+    int wc2 = 1;
+    int regb = std::max(ring, 2 * 64 * rowb + 2 * nred * 128);
+    if (rega + regb + tail > budget) { wc2 = 0; regb = std::max(ring, 64 * rowb + 2 * nred * 128); }
     g->patch_bytes = patch;
     g->rega_bytes = rega;
-    g->lds_bytes = rega + ring + 64 * rowb + (cmid + 4 * cmid + nred) * 5 + 16;
+    g->nw = nw;
+    g->wc2 = wc2;
+    g->lds_bytes = rega + regb + tail;
     return g->lds_bytes <= 160 * 1024;
 }
 
@@ -426,26 +439,55 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
     const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
-    dim3 grid((unsigned)((M + 127) / 128));
-#define FAV_TAIL(CMID_, NRED_, H3_, NS_)                                                                              \
+    const int bm = 32 * g.nw;
+    const long long nblocks = (M + bm - 1) / bm;
+    dim3 grid((unsigned)nblocks);
+    p.dbg = nullptr;
+    static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
+    if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)nblocks * 64); (void)hipMemset(p.dbg, 0, (size_t)nblocks * 64); }
+    auto dbg_report = [&]() {
+        if (!p.dbg) return;
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> t((size_t)nblocks * 8);
+        (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(p.dbg);
+        unsigned long long lo = ~0ull, hi = 0;
+        double ph[5] = {0, 0, 0, 0, 0};
+        for (long long i = 0; i < nblocks; ++i) {
+            lo = std::min(lo, t[i * 8]); hi = std::max(hi, t[i * 8 + 5]);
+            unsigned long long prev = t[i * 8];
+            for (int j = 0; j < 5; ++j) { const unsigned long long c = t[i * 8 + j + 1] ? t[i * 8 + j + 1] : prev; ph[j] += (double)(c - prev); prev = c; }
+        }
+        const double span = (double)(hi - lo), life = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
+        fprintf(stderr, "[tail dbg] blocks %lld x %d px, Cmid %d Nred %d 3x3 %d: span %.1f us; per block: patch wait %.2f us, 3x3 loop %.2f us, "
+                        "T2 + first weights %.2f us, chunks %.2f us, tail %.2f us; resident blocks/CU %.2f\n", nblocks, bm, cmid, nred, (int)has3x3,
+                span / 100.0, ph[0] / nblocks / 100.0, ph[1] / nblocks / 100.0, ph[2] / nblocks / 100.0, ph[3] / nblocks / 100.0,
+                ph[4] / nblocks / 100.0, life / span / 256.0);
+    };
+#define FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, WC2_)                                                                   \
     do {                                                                                                              \
         static DeviceFlags attr_set;                                                                                  \
         if (!attr_set.test_current()) {                                                                               \
-            if (hipFuncSetAttribute((const void*)bottleneck_tail_kernel<CMID_, NRED_, H3_, NS_>,                      \
+            if (hipFuncSetAttribute((const void*)bottleneck_tail_kernel<CMID_, NRED_, H3_, NS_, NW_, WC2_>,           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)            \
                 return "bottleneck tail: cannot reserve LDS";                                                         \
             attr_set.set_current();                                                                                   \
         }                                                                                                             \
-        hipLaunchKernelGGL((bottleneck_tail_kernel<CMID_, NRED_, H3_, NS_>), grid, dim3(256), g.lds_bytes, s, p, g.patch_bytes); \
+        hipLaunchKernelGGL((bottleneck_tail_kernel<CMID_, NRED_, H3_, NS_, NW_, WC2_>), grid, dim3(NW_ * 64), g.lds_bytes, s, p, g.patch_bytes); \
+        dbg_report();                                                                                                 \
         return nullptr;                                                                                               \
     } while (0)
+#define FAV_TAIL_W(CMID_, NRED_, H3_, NS_, NW_) do { if (g.wc2) FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, true); else FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, false); } while (0)
+#define FAV_TAIL_N(CMID_, NRED_, H3_, NS_) do { if (g.nw == 4) FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 4); else FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 8); } while (0)
     if (cmid == 64) {
-        if (has3x3) { if (nred == 0) FAV_TAIL(64, 0, true, 3); if (nred == 64) FAV_TAIL(64, 64, true, 3); if (nred == 128) FAV_TAIL(64, 128, true, 3); }
-        else { if (nred == 0) FAV_TAIL(64, 0, false, 3); if (nred == 64) FAV_TAIL(64, 64, false, 3); if (nred == 128) FAV_TAIL(64, 128, false, 3); }
+        if (has3x3) { if (nred == 0) FAV_TAIL_N(64, 0, true, 3); if (nred == 64) FAV_TAIL_N(64, 64, true, 3); if (nred == 128) FAV_TAIL_N(64, 128, true, 3); }
+        else { if (nred == 0) FAV_TAIL_N(64, 0, false, 3); if (nred == 64) FAV_TAIL_N(64, 64, false, 3); if (nred == 128) FAV_TAIL_N(64, 128, false, 3); }
     } else {
-        if (has3x3) { if (nred == 0) FAV_TAIL(128, 0, true, 2); if (nred == 128) FAV_TAIL(128, 128, true, 2); }
-        else { if (nred == 0) FAV_TAIL(128, 0, false, 2); if (nred == 128) FAV_TAIL(128, 128, false, 2); }
+        if (has3x3) { if (nred == 0) FAV_TAIL_W(128, 0, true, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, true, 2, 8); }
+        else { if (nred == 0) FAV_TAIL_W(128, 0, false, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, false, 2, 8); }
     }
+#undef FAV_TAIL_N
+#undef FAV_TAIL_W
 #undef FAV_TAIL
     return "bottleneck tail: unsupported shape";
 }

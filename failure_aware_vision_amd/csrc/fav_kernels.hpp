@@ -917,20 +917,25 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
 // read X, write Y, read Y, write t1'); fused it moves 4.0 MB (read t1 and X, write Y and t1'): conv_b's output
 // never leaves the CU, and Y is consumed by conv_a while its 64-channel chunk is still in LDS.
 //
-// A block of 4 waves (2 x 2) owns 128 consecutive output pixels m (flattened frame, y, x):
-//   P1  conv_b exactly as conv3x3_halo_kernel (patch staged once, weights through a ring, same k order);
-//   P1e T2 = bf16(relu(acc + bias_b)) -> LDS in the MFMA operand layout; every wave then keeps the fragments of
-//       its 64 pixels (all CMID k) in registers, which frees the LDS for P2;
-//   P2  for each 64-channel chunk j of Y:  acc2 = T2 x Wc[j]^T  (K = CMID);  epilogue through an fp32 LDS stage
-//       (bias + residual + ReLU + Philox dropout + one bf16 rounding: the generic kernel's epilogue), Y chunk ->
-//       HBM and -> LDS in operand layout;  acc3 += Ychunk x Wa[:, 64j..64j+63]^T   (the K loop of conv_a, k
-//       ascending, 64 per chunk - the order conv_igemm_kernel uses, so the sums are bit-identical to it);
-//   P3  t1' = bf16(relu(acc3 + bias_a)) -> HBM.
-// Every load is an LDS-DMA or a raw buffer load whose descriptor ends at the tile's last valid row (rows beyond
-// M read zeros / are not written), and every store is an unconditional raw buffer store, so the NUMBER of vector
-// memory operations per chunk is a compile-time constant: the one wait per chunk is a counted
-// `s_waitcnt vmcnt(8)` (4 residual loads for chunk j+1 and 4 stores of chunk j stay in flight) and no store is
-// ever waited for.  The next chunk's weights and residual are requested one chunk ahead.
+// A block of NW waves owns BM = 32*NW consecutive output pixels m (flattened frame, y, x):
+//   P1  conv_b exactly as conv3x3_halo_kernel (patch staged once, weights through a ring, same k order), waves
+//       BM/64 (pixels) x 2 (channels);
+//   P1e T2 = bf16(relu(acc + bias_b)) -> LDS in the MFMA operand layout; from here on wave w OWNS the 32 pixel
+//       rows [32w, 32w + 32) with all their channels, and keeps their T2 fragments (all CMID k) in registers;
+//   P2  for each 64-channel chunk j of Y:  acc2 = T2 x Wc[j]^T  (K = CMID).  The rows of Wc[j] are staged in the
+//       order 16*(i/4) + 4*a + i%4 (a = MFMA tile, i = its row), so lane (pixel frow, quad fq) ends up with the 16
+//       CONSECUTIVE channels 16*fq .. 16*fq+15 of its pixel in registers: bias + residual + ReLU + Philox dropout
+//       (one call = exactly its 16 draws) + one bf16 rounding happen in registers, two 16-B stores send the chunk
+//       to HBM and two ds_write_b128 put it into the wave's own rows of the Y-chunk LDS image; then
+//       acc3 += Ychunk x Wa[:, 64j..64j+63]^T on the wave's own rows - no workgroup barrier, no fp32 staging.
+//       (k ascending, 64 per chunk: the order conv_igemm_kernel uses, so all sums are bit-identical to it.)
+//   P3  t1' = bf16(relu(acc3 + bias_a)) from registers (same row order trick for Wa) -> HBM.
+// The weights of chunk j+1 (Wc, Wa: double-buffered) and its residual are requested at the start of chunk j; the
+// only workgroup barrier of a chunk is the one that publishes those weight pieces.  Every load is an LDS-DMA or
+// a raw buffer load whose descriptor ends at the tile's last valid row (rows beyond M read zeros / are not
+// written), and every store is an unconditional raw buffer store, so the NUMBER of vector memory operations per
+// chunk is a compile-time constant: the one wait per chunk is a counted `s_waitcnt vmcnt(N)` that leaves the
+// residual loads of chunk j+1 and the stores of chunk j in flight, and no store is ever waited for.
 // ---------------------------------------------------------------------------
 struct TailParams {
     const uint16_t* t1;       // [M][CMID]: input of conv_b (HAS3X3) or of conv_c (!HAS3X3)
@@ -941,9 +946,10 @@ struct TailParams {
     const uint16_t* wa; const float* bias_a;     // [NRED][COUT]
     uint16_t* t1n;            // [M][NRED]
     int H, W, HW, M;
-    int rega_bytes;           // LDS region A: patch | T2 tile | fp32 stage + Y chunk
+    int rega_bytes;           // LDS region A: patch | T2 tile | Y chunk
     DropParams drop;
     FastDiv div_hw, div_w;
+    unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
 };
 
 // raw workgroup barrier: this wave's LDS operations retired, no vmcnt drain (stores and prefetches stay in flight)
@@ -954,42 +960,51 @@ struct TailParams {
         asm volatile("" ::: "memory");                          \
     } while (0)
 
-template <int CMID, int NRED, bool HAS3X3, int NS>
-__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
+// LDS row r (tile a = r/16 of a 64-row group, MFMA row i = r%16) holds weight row 16*(i/4) + 4*a + i%4 of the group
+__device__ __forceinline__ int tail_row_perm(int r) {
+    const int g = r & ~63, a = (r >> 4) & 3, i = r & 15;
+    return g + 16 * (i >> 2) + 4 * a + (i & 3);
+}
+
+template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2>
+__global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
     constexpr int COUT = 4 * CMID;
-    constexpr int BM = 128, NWAVES = 4;
+    constexpr int BM = 32 * NW, NT = NW * 64;      // every wave owns 32 pixel rows in P2
     constexpr int ROWB = CMID * 2;               // bytes per pixel of t1 / T2
     constexpr int CPR = ROWB / 16;               // 16-B chunks per pixel (8 or 16)
     constexpr int PROWS = 1024 / ROWB;           // pixels per 1-KiB LDS-DMA piece
     constexpr int CB = CMID / 64;                // 64-channel K tiles per tap
     constexpr int NKT = 9 * CB;
-    constexpr int TM = 4;
-    constexpr int TN1 = CMID / 32;               // conv_b: wave tile 64 px x CMID/2 channels
+    constexpr int TM = 4;                        // conv_b: BM/64 x 2 waves, wave tile 64 px x CMID/2 channels
+    constexpr int WN1 = 2;
+    constexpr int TN1 = CMID / WN1 / 16;
     constexpr int SLOT = CMID * 128;             // one K tile of Wb: CMID rows x 64 k
-    constexpr int BR = SLOT / 1024 / NWAVES;     // LDS-DMA pieces per wave per K tile of Wb
+    constexpr int BR = SLOT / 1024 / NW;         // LDS-DMA pieces per wave per K tile of Wb
     constexpr int NCHUNK = COUT / 64;
     constexpr int KS2 = CMID / 32;               // 32-deep k steps of conv_c
-    constexpr int TN3 = NRED / 32;               // conv_a: wave tile 64 px x NRED/2
-    constexpr int STG_LD = 68, STG_BYTES = 64 * STG_LD * 4;   // fp32 stage of one 64-row half of a 64-channel chunk
-    constexpr int AREA_C = 64 * ROWB;            // Wc chunk: 64 rows x CMID k, as CB sub tiles of 64 x 64
-    constexpr int AREA_A = NRED * 128;           // Wa chunk: NRED rows x 64 k
+    constexpr int RP = BM / NW;                  // pixel rows a wave owns in P2
+    constexpr int TM2 = RP / 16;
+    constexpr int G3 = NRED / 64;                // 64-channel groups of conv_a's output
+    constexpr int WC_BYTES = 64 * ROWB;          // Wc chunk: 64 rows x CMID k, as CB sub tiles of 64 x 64
+    constexpr int WA_BYTES = NRED * 128;         // Wa chunk: NRED rows x 64 k
+    constexpr int WCN = WC2 ? 2 : 1;             // Wc buffers: 2 = requested a chunk ahead; 1 = requested behind a barrier after step A
+    constexpr int P2W = WCN * WC_BYTES + 2 * WA_BYTES;
     constexpr int RING = HAS3X3 ? NS * SLOT : 0;
-    constexpr int RING_BYTES = RING > AREA_A ? RING : AREA_A;
-    static_assert(BR >= 1 && (NRED == 0 || TN3 >= 1), "tile shape");
+    constexpr int REGB = RING > P2W ? RING : P2W;
+    constexpr int WC_PIECES = WC_BYTES / 1024, WA_PIECES = WA_BYTES / 1024;
+    constexpr int WC_PW = (WC_PIECES + NW - 1) / NW, WA_PW = (WA_PIECES + NW - 1) / NW;   // pieces per wave (the last may be skipped)
+    static_assert(BR >= 1 && TN1 >= 1 && TM2 >= 1 && WC_PIECES % NW == 0 && (NRED == 0 || WA_PIECES % NW == 0), "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-    // [region A | weight ring (P1) / Wa chunk (P2) | Wc chunk | biases (16-channel chunks 20 floats apart) | 16 zero bytes]
-    unsigned char* const stg_b = tsm;                              // P2: fp32 stage
-    unsigned char* const ych = tsm + STG_BYTES;                    // P2: Y chunk [128][64] bf16, chunk ^= row & 7
-    unsigned char* const ring = tsm + p.rega_bytes;
-    unsigned char* const area_a = ring;
-    unsigned char* const area_c = ring + RING_BYTES;
-    float* const bias_b_s = (float*)(area_c + AREA_C);
+    // [region A | region B: weight ring (P1) / Wc x2, Wa x2 (P2) | biases (16-channel chunks 20 floats apart) | 16 zero bytes]
+    unsigned char* const ych = tsm;                                // P2: Y chunk [BM][64] bf16, chunk ^= row & 7
+    unsigned char* const regb = tsm + p.rega_bytes;
+    float* const bias_b_s = (float*)(regb + REGB);
     float* const bias_c_s = bias_b_s + (CMID / 16) * 20;
     float* const bias_a_s = bias_c_s + (COUT / 16) * 20;
-    const uint32_t zero_off = (uint32_t)(p.rega_bytes + RING_BYTES + AREA_C + (CMID + COUT + NRED) * 5);
+    const uint32_t zero_off = (uint32_t)(p.rega_bytes + REGB + (CMID + COUT + NRED) * 5);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN1, wn = wave % WN1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int frow = lane & 15, fq = lane >> 4;
     const int nwg = gridDim.x;
@@ -1000,45 +1015,44 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
     }
     const int m0 = tile * BM;
     const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull] = wall_clock64();
 
     // ---- P0: biases (plain loads, issued before any DMA), descriptors, the first requests -----------------
-    if (HAS3X3) for (int i = tid; i < CMID; i += 256) bias_b_s[(i >> 4) * 20 + (i & 15)] = p.bias_b[i];
-    for (int i = tid; i < COUT; i += 256) bias_c_s[(i >> 4) * 20 + (i & 15)] = p.bias_c[i];
-    if (NRED > 0) for (int i = tid; i < NRED; i += 256) bias_a_s[(i >> 4) * 20 + (i & 15)] = p.bias_a[i];
+    if (HAS3X3) for (int i = tid; i < CMID; i += NT) bias_b_s[(i >> 4) * 20 + (i & 15)] = p.bias_b[i];
+    for (int i = tid; i < COUT; i += NT) bias_c_s[(i >> 4) * 20 + (i & 15)] = p.bias_c[i];
+    if (NRED > 0) for (int i = tid; i < NRED; i += NT) bias_a_s[(i >> 4) * 20 + (i & 15)] = p.bias_a[i];
     if (tid < 4) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)tsm);
-    const uint32_t lds_ring = lds_base + (uint32_t)p.rega_bytes;
-    const uint32_t lds_area_c = lds_ring + RING_BYTES;
+    const uint32_t lds_regb = lds_base + (uint32_t)p.rega_bytes;
     constexpr uint32_t OOB = 0x80000000u;
-    // weights: rows of 128 B (64 k) per piece of 8 rows; lane -> row l>>3, physical slot l&7 holds chunk (l&7)^(row&7)
+    // weights: rows of 128 B (64 k), a piece = 8 rows; lane -> row l>>3, physical slot l&7 holds chunk (l&7)^(row&7)
     const int wrow = lane >> 3, wch = (lane & 7) ^ (wrow & 7);
     const __amdgpu_buffer_rsrc_t srd_wc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wc, 0, COUT * CMID * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_wa = __builtin_amdgcn_make_buffer_rsrc((void*)p.wa, 0, NRED > 0 ? NRED * COUT * 2 : 16, 0x00020000);
-// Wc chunk J (64 rows x CMID k): CB sub tiles [64][64]; 8*CB pieces, wave w takes pieces w, w+4, ...
+// Wc chunk J (64 rows x CMID k) -> buffer J % WCN: CB sub tiles [64][64], LDS row r <- weight row tail_row_perm(r)
 #define FAV_T_STAGE_WC(J)                                                                                        \
     do {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 2 * CB; ++i) {                                                     \
-            const int pc = wave_u + i * NWAVES;            /* piece: sub tile pc / 8, rows (pc % 8) * 8 .. + 7 */ \
+        _Pragma("unroll") for (int i = 0; i < WC_PW; ++i) {                                                      \
+            const int pc = wave_u + i * NW;                /* piece: sub tile pc / 8, rows (pc % 8) * 8 .. + 7 */ \
             const int sub = pc >> 3, r0 = (pc & 7) * 8;                                                          \
-            lds_dma16(srd_wc, (uint32_t)((((J) * 64 + r0 + wrow) * CMID + sub * 64 + wch * 8) * 2), 0u,         \
-                      __builtin_amdgcn_readfirstlane(lds_area_c + (uint32_t)pc * 1024u));                        \
+            lds_dma16(srd_wc, (uint32_t)((((J) * 64 + tail_row_perm(r0 + wrow)) * CMID + sub * 64 + wch * 8) * 2), 0u, \
+                      __builtin_amdgcn_readfirstlane(lds_regb + (uint32_t)(((J) % WCN) * WC_BYTES + pc * 1024)));  \
         }                                                                                                        \
     } while (0)
-// Wa chunk J (NRED rows x 64 k): NRED/8 pieces
+// Wa chunk J (NRED rows x 64 k) -> buffer J & 1
 #define FAV_T_STAGE_WA(J)                                                                                        \
     do {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < NRED / 32; ++i) {                                                  \
-            const int pc = wave_u + i * NWAVES;                                                                  \
-            lds_dma16(srd_wa, (uint32_t)(((pc * 8 + wrow) * COUT + wch * 8) * 2), (uint32_t)((J) * 128),        \
-                      __builtin_amdgcn_readfirstlane(lds_ring + (uint32_t)pc * 1024u));                          \
+        _Pragma("unroll") for (int i = 0; i < WA_PW; ++i) {                                                      \
+            const int pc = wave_u + i * NW;                                                                      \
+            lds_dma16(srd_wa, (uint32_t)((tail_row_perm(pc * 8 + wrow) * COUT + wch * 8) * 2), (uint32_t)((J) * 128), \
+                      __builtin_amdgcn_readfirstlane(lds_regb + (uint32_t)(WCN * WC_BYTES + ((J) & 1) * WA_BYTES + pc * 1024))); \
         }                                                                                                        \
     } while (0)
-    FAV_T_STAGE_WC(0);   // oldest request of the block: landed long before P2 reads it
 
     const int W = p.W;
-    f32x4_t acc[TN1][TM];
     if (HAS3X3) {
+        f32x4_t acc[TN1][TM];
         // ---- patch: flattened input pixels [m0 - W - 1, m0 + BM + W + 1), all CMID channels --------------------
         const long long g0 = (long long)m0 - W - 1;
         const long long gbase = g0 > 0 ? g0 : 0;
@@ -1046,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
         {
             const int npieces = patch_bytes >> 10;
             const int lrow = lane / CPR, lslot = lane % CPR;
-            for (int j = wave_u; j < npieces; j += NWAVES) {
+            for (int j = wave_u; j < npieces; j += NW) {
                 const int q = j * PROWS + lrow;
                 const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
                 const long long g = g0 + q;
@@ -1059,7 +1073,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
         uint32_t b_voff[BR];
 #pragma unroll
         for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)((((wave * BR + i) * 8 + wrow) * (9 * CMID) + wch * 8) * 2);
-        const uint32_t lds_b = lds_ring + wave_u * (BR * 1024);
+        const uint32_t lds_b = lds_regb + wave_u * (BR * 1024);
 #define FAV_T_HSTAGE(BUF, KT)                                                                         \
     do {                                                                                              \
         _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                \
@@ -1091,11 +1105,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
             for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
         __syncthreads();
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 1] = wall_clock64();
         int cur = 0, nxt = NS - 1;
         int tap = 0, cb = 0, tapoff = 0, tr = 0, ts = 0;
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt + NS - 1 < NKT) FAV_T_HSTAGE(nxt, kt + NS - 1);
-            const unsigned char* Bs = ring + cur * SLOT;
+            const unsigned char* Bs = regb + cur * SLOT;
             uint32_t a_addr[TM];
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
@@ -1114,7 +1129,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
                 }
 #pragma unroll
                 for (int a = 0; a < TN1; ++a) {
-                    const int row = wn * (CMID / 2) + a * 16 + frow;
+                    const int row = wn * (CMID / WN1) + a * 16 + frow;
                     fw[a] = *(const uint4*)(Bs + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
                 }
 #pragma unroll
@@ -1140,13 +1155,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
 #undef FAV_T_HSTAGE
-        // ---- P1e: T2 = bf16(relu(acc + bias_b)) -> LDS [128][CMID], operand layout (every wave is past the patch) ----
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 2] = wall_clock64();
+        // the weight ring is free: request the first chunk's weights (region B is theirs from here on)
+        FAV_T_STAGE_WC(0);
+        if (NRED > 0) FAV_T_STAGE_WA(0);
+        // ---- P1e: T2 = bf16(relu(acc + bias_b)) -> LDS [BM][CMID], operand layout (every wave is past the patch) ----
 #pragma unroll
         for (int a = 0; a < TN1; ++a)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int row = wm * 64 + b * 16 + frow;
-                const int c0 = wn * (CMID / 2) + a * 16 + fq * 4;
+                const int c0 = wn * (CMID / WN1) + a * 16 + fq * 4;
                 const float4 bq = *(const float4*)(bias_b_s + (c0 >> 4) * 20 + (c0 & 15));
                 const float v0 = fmaxf(__fadd_rn(acc[a][b][0], bq.x), 0.f), v1 = fmaxf(__fadd_rn(acc[a][b][1], bq.y), 0.f);
                 const float v2 = fmaxf(__fadd_rn(acc[a][b][2], bq.z), 0.f), v3 = fmaxf(__fadd_rn(acc[a][b][3], bq.w), 0.f);
@@ -1154,139 +1173,135 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
                 *(uint2*)(tsm + row * ROWB + (((c0 >> 3) ^ sw) << 4) + ((c0 >> 2) & 1) * 8) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
             }
     } else {
-        // ---- conv_c alone: its input tile [128][CMID] straight into the operand layout ------------------------
+        // ---- conv_c alone: its input tile [BM][CMID] straight into the operand layout -------------------------
+        FAV_T_STAGE_WC(0);
+        if (NRED > 0) FAV_T_STAGE_WA(0);
         const __amdgpu_buffer_rsrc_t srd_a =
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + (long long)m0 * CMID), 0, rows_valid * ROWB, 0x00020000);
         const int lrow = lane / CPR, lslot = lane % CPR;
 #pragma unroll
-        for (int i = 0; i < BM * ROWB / 1024 / NWAVES; ++i) {
-            const int j = wave_u + i * NWAVES;
+        for (int i = 0; i < BM * ROWB / 1024 / NW; ++i) {
+            const int j = wave_u + i * NW;
             const int q = j * PROWS + lrow;
             const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
             lds_dma16(srd_a, (uint32_t)(q * ROWB + ((lslot ^ sw) << 4)), 0u, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)j * 1024u));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // T2 tile (DMA path) and the first chunk's weights
     __syncthreads();
-    // every wave keeps the operand fragments of its 64 pixels (all CMID k) in registers: region A is free after this
-    uint4 t2f[TM][KS2];
+    // wave w owns pixel rows [w*RP, w*RP + RP): their T2 fragments (all CMID k) live in registers from here on
+    uint4 t2f[TM2][KS2];
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int row = wm * 64 + b * 16 + frow;
+    for (int b = 0; b < TM2; ++b) {
+        const int row = wave * RP + b * 16 + frow;
         const int sw = (CPR == 8) ? (row & 7) : ((row & 7) | ((row & 1) << 3));
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) t2f[b][ks] = *(const uint4*)(tsm + row * ROWB + (((ks * 4 + fq) ^ sw) << 4));
     }
-    __syncthreads();
+    __syncthreads();                                      // region A becomes the Y-chunk image
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 3] = wall_clock64();
 
     // ---- P2 ---------------------------------------------------------------------------------------------------
-    // epilogue geometry: 64 rows x 4 chunks of 16 channels per half -> one item per thread and half
-    const int ec = tid & 3, er = tid >> 2;
+    // lane (frow, fq) finishes channels 64j + 16fq .. + 15 of pixel rows wave*RP + b*16 + frow
     const __amdgpu_buffer_rsrc_t srd_res =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_y =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
-    u32x4_t rnext[2][2], rcur[2][2];
+    u32x4_t rnext[TM2][2], rcur[TM2][2];
 #define FAV_T_LOAD_RES(J)                                                                                        \
-    _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                           \
-        const int off = ((hf * 64 + er) * COUT + (J) * 64 + ec * 16) * 2;                                        \
-        rnext[hf][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off, 0, 0);                                \
-        rnext[hf][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off + 16, 0, 0);                           \
+    _Pragma("unroll") for (int b = 0; b < TM2; ++b) {                                                            \
+        const int off = ((wave * RP + b * 16 + frow) * COUT + (J) * 64 + fq * 16) * 2;                           \
+        rnext[b][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off, 0, 0);                                 \
+        rnext[b][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off + 16, 0, 0);                            \
     }
     FAV_T_LOAD_RES(0)
-    // dropout: virtual frame and pixel of this thread's two rows
-    uint32_t drop_v[2], drop_pix[2];
+    uint32_t drop_v[TM2], drop_pix[TM2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const uint32_t m = (uint32_t)(m0 + hf * 64 + er);
+    for (int b = 0; b < TM2; ++b) {
+        const uint32_t m = (uint32_t)(m0 + wave * RP + b * 16 + frow);
         const uint32_t vl = fastdiv(m, p.div_hw);
-        drop_v[hf] = (uint32_t)p.drop.v0 + vl;
-        drop_pix[hf] = m - vl * (uint32_t)p.HW;
+        drop_v[b] = (uint32_t)p.drop.v0 + vl;
+        drop_pix[b] = m - vl * (uint32_t)p.HW;
     }
-    f32x4_t acc3[TN3 > 0 ? TN3 : 1][TM];
+    constexpr int NA3 = NRED > 0 ? NRED / 16 : 1;
+    f32x4_t acc3[NA3][TM2];
 #pragma unroll
-    for (int a = 0; a < (TN3 > 0 ? TN3 : 1); ++a)
+    for (int a = 0; a < NA3; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc3[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float* const stg = (float*)stg_b;
+        for (int b = 0; b < TM2; ++b) acc3[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // Fully unrolled: in straight-line code hipcc counts its own loads and stores exactly, so the wait it places in
-    // front of the residual pin below is vmcnt(4) (the previous chunk's 4 stores stay in flight); as a loop it
-    // merges the first iteration's state and falls back to vmcnt(0), i.e. a write round trip per chunk.
+    // front of the residual pin below leaves the previous chunk's stores in flight; as a loop it merges the first
+    // iteration's state and falls back to vmcnt(0), i.e. a write round trip per chunk.
 #pragma unroll
     for (int j = 0; j < NCHUNK; ++j) {
-        // -- A: acc2 = T2 x Wc[j]^T : wave tile 64 px x 32 channels (channels wn*32 .. +31 of the chunk)
-        f32x4_t acc2[2][TM];
+        const unsigned char* const wcb = regb + (j % WCN) * WC_BYTES;
+        const unsigned char* const wab = regb + WCN * WC_BYTES + (j & 1) * WA_BYTES;
+        // residual of THIS chunk has landed; then the requests of the NEXT chunk (the other weight buffers: every
+        // wave is past chunk j-1, the barrier at its end says so)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < TM2; ++b) {
+            asm volatile("" : "+v"(rnext[b][0]), "+v"(rnext[b][1]));
+            rcur[b][0] = rnext[b][0];
+            rcur[b][1] = rnext[b][1];
+        }
+        if (j + 1 < NCHUNK) {
+            if (WC2) FAV_T_STAGE_WC(j + 1);
+            if (NRED > 0) FAV_T_STAGE_WA(j + 1);
+            FAV_T_LOAD_RES(j + 1)
+        }
+        // -- A: acc2 = T2 x Wc[j]^T : RP pixels x 64 channels
+        f32x4_t acc2[4][TM2];
 #pragma unroll
-            for (int b = 0; b < TM; ++b) acc2[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < TM2; ++b) acc2[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
-            uint4 fw[2];
+            uint4 fw[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int row = wn * 32 + a * 16 + frow;
-                fw[a] = *(const uint4*)(area_c + (ks >> 1) * 8192 + row * 128 + ((((ks & 1) * 4 + fq) ^ (row & 7)) << 4));
+            for (int a = 0; a < 4; ++a) {
+                const int row = a * 16 + frow;
+                fw[a] = *(const uint4*)(wcb + (ks >> 1) * 8192 + row * 128 + ((((ks & 1) * 4 + fq) ^ (row & 7)) << 4));
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < TM; ++b) {
+                for (int b = 0; b < TM2; ++b) {
                     union { uint4 u; bf16x8_t v; } ua, ub;
                     ua.u = fw[a];
                     ub.u = t2f[b][ks];
                     acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc2[a][b], 0, 0, 0);
                 }
         }
-        // -- B: the two 64-row halves through the fp32 stage
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half > 0) FAV_BAR();            // everyone has read the previous half
-            if (wm == half) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < TM; ++b)
-                        *(f32x4_t*)(stg + (b * 16 + frow) * STG_LD + wn * 32 + a * 16 + fq * 4) = acc2[a][b];
-            }
+        if (!WC2 && j + 1 < NCHUNK) {      // single Wc buffer: every wave has read Wc[j], the next chunk's may overwrite it
             FAV_BAR();
-            if (half == 0) {
-                // the residual of THIS chunk has landed (the compiler's wait leaves only the previous chunk's 4 stores
-                // in flight); then the requests of the NEXT chunk: Wa[j], Wc[j+1] (LDS-DMA), residual j+1 (registers)
+            FAV_T_STAGE_WC(j + 1);
+        }
+        // -- B: epilogue in registers: acc2[a][b][r] is channel 64j + 16fq + 4a + r of pixel row b*16 + frow
+        {
+            float bia[16];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    asm volatile("" : "+v"(rnext[hf][0]), "+v"(rnext[hf][1]));
-                    rcur[hf][0] = rnext[hf][0];
-                    rcur[hf][1] = rnext[hf][1];
-                }
-                if (NRED > 0) FAV_T_STAGE_WA(j);
-                if (j + 1 < NCHUNK) {
-                    FAV_T_STAGE_WC(j + 1);
-                    FAV_T_LOAD_RES(j + 1)
-                }
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4*)(bias_c_s + (j * 4 + fq) * 20 + 4 * q);
+                bia[4 * q] = bq.x; bia[4 * q + 1] = bq.y; bia[4 * q + 2] = bq.z; bia[4 * q + 3] = bq.w;
             }
-            {
-                const int n = j * 64 + ec * 16;                 // first of this thread's 16 channels
+#pragma unroll
+            for (int b = 0; b < TM2; ++b) {
+                const int row = wave * RP + b * 16 + frow;
+                const int n = j * 64 + fq * 16;
                 uint32_t draws[4] = {~0u, ~0u, ~0u, ~0u};
                 if (p.drop.site >= 0) {
-                    const uint32_t chunk = (uint32_t)(((long long)drop_pix[half] * COUT + n) >> 4);
-                    const uint4 w4 = drop_draws16(p.drop, drop_v[half], chunk);
+                    const uint32_t chunk = (uint32_t)(((long long)drop_pix[b] * COUT + n) >> 4);
+                    const uint4 w4 = drop_draws16(p.drop, drop_v[b], chunk);
                     draws[0] = w4.x; draws[1] = w4.y; draws[2] = w4.z; draws[3] = w4.w;
                 }
-                const float* bsrc = bias_c_s + (j * 4 + ec) * 20;
-                const int row = half * 64 + er;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float v[8];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float4 t4 = *(const float4*)(stg + er * STG_LD + ec * 16 + 8 * g + 4 * q);
-                        const float4 bq = *(const float4*)(bsrc + 8 * g + 4 * q);
-                        v[4 * q] = __fadd_rn(t4.x, bq.x); v[4 * q + 1] = __fadd_rn(t4.y, bq.y);
-                        v[4 * q + 2] = __fadd_rn(t4.z, bq.z); v[4 * q + 3] = __fadd_rn(t4.w, bq.w);
-                    }
-                    const uint32_t rw[4] = {rcur[half][g][0], rcur[half][g][1], rcur[half][g][2], rcur[half][g][3]};
+                    for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc2[2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]);
+                    const uint32_t rw[4] = {rcur[b][g][0], rcur[b][g][1], rcur[b][g][2], rcur[b][g][3]};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         v[2 * k] = __fadd_rn(v[2 * k], bf16_bits_to_f32(rw[k] & 0xFFFFu));
@@ -1300,82 +1315,78 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const TailParam
                     }
                     const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                     __builtin_amdgcn_raw_buffer_store_b128(o, srd_y, (row * COUT + n + 8 * g) * 2, 0, 0);
-                    if (NRED > 0) *(u32x4_t*)(ych + row * 128 + (((2 * ec + g) ^ (row & 7)) << 4)) = o;
+                    if (NRED > 0) *(u32x4_t*)(ych + row * 128 + (((2 * fq + g) ^ (row & 7)) << 4)) = o;
                 }
             }
         }
-        // the requests issued in front of this chunk's 4 stores (and, except in the last chunk, 4 residual loads) have landed
-        if (j + 1 < NCHUNK) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        FAV_BAR();
-        // -- C: acc3 += Ychunk x Wa[:, 64j .. 64j+63]^T
+        // -- C: acc3 += Ychunk (this wave's own rows: its LDS writes are in order, no barrier) x Wa[:, 64j .. 64j+63]^T
         if constexpr (NRED > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                uint4 fy[TM], fw[TN3 > 0 ? TN3 : 1];
+                uint4 fy[TM2];
 #pragma unroll
-                for (int b = 0; b < TM; ++b) {
-                    const int row = wm * 64 + b * 16 + frow;
+                for (int b = 0; b < TM2; ++b) {
+                    const int row = wave * RP + b * 16 + frow;
                     fy[b] = *(const uint4*)(ych + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
                 }
 #pragma unroll
-                for (int a = 0; a < TN3; ++a) {
-                    const int row = wn * (NRED / 2) + a * 16 + frow;
-                    fw[a] = *(const uint4*)(area_a + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
-                }
+                for (int a = 0; a < NA3; ++a) {
+                    const int row = a * 16 + frow;
+                    union { uint4 u; bf16x8_t v; } ua;
+                    ua.u = *(const uint4*)(wab + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
 #pragma unroll
-                for (int a = 0; a < TN3; ++a)
-#pragma unroll
-                    for (int b = 0; b < TM; ++b) {
-                        union { uint4 u; bf16x8_t v; } ua, ub;
-                        ua.u = fw[a];
+                    for (int b = 0; b < TM2; ++b) {
+                        union { uint4 u; bf16x8_t v; } ub;
                         ub.u = fy[b];
                         acc3[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc3[a][b], 0, 0, 0);
                     }
+                }
             }
+        }
+        // the next chunk's weight pieces of this wave have landed (its residual loads and this chunk's stores stay in
+        // flight), then the barrier publishes every wave's pieces and retires this chunk's reads of the current buffers
+        if (j + 1 < NCHUNK) {
+            // WC2: the youngest operations are the next residual loads and this chunk's stores; otherwise the Wc pieces
+            // were issued after the residual loads, so only the stores may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC2 ? 4 * TM2 : 2 * TM2) : "memory");
+            FAV_BAR();
         }
     }
 #undef FAV_T_LOAD_RES
 #undef FAV_T_STAGE_WC
 #undef FAV_T_STAGE_WA
 
-    // ---- P3: t1' = bf16(relu(acc3 + bias_a)) -> HBM, 64 rows at a time through the stage (row stride NRED + 4) ----
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 4] = wall_clock64();
+    // ---- P3: t1' = bf16(relu(acc3 + bias_a)): lane holds channels 64*g3 + 16fq .. + 15 of its pixel rows ----------
     if constexpr (NRED > 0) {
-        constexpr int LD3 = NRED + 4, NCH3 = NRED / 16;
-        constexpr int RPP3 = (256 / NCH3 > 64) ? 64 : 256 / NCH3, NPASS3 = 64 / RPP3;
         const __amdgpu_buffer_rsrc_t srd_t =
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1n + (long long)m0 * NRED), 0, rows_valid * NRED * 2, 0x00020000);
-        const int ec3 = tid % NCH3, er3 = tid / NCH3;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            FAV_BAR();                           // the last chunk's reads of the Y chunk / the previous half are done
-            if (wm == half) {
+        for (int g3 = 0; g3 < G3; ++g3) {
+            float bia[16];
 #pragma unroll
-                for (int a = 0; a < TN3; ++a)
-#pragma unroll
-                    for (int b = 0; b < TM; ++b)
-                        *(f32x4_t*)(stg + (b * 16 + frow) * LD3 + wn * (NRED / 2) + a * 16 + fq * 4) = acc3[a][b];
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4*)(bias_a_s + (g3 * 4 + fq) * 20 + 4 * q);
+                bia[4 * q] = bq.x; bia[4 * q + 1] = bq.y; bia[4 * q + 2] = bq.z; bia[4 * q + 3] = bq.w;
             }
-            FAV_BAR();
 #pragma unroll
-            for (int pass = 0; pass < NPASS3; ++pass) {
-                const int ml = er3 + pass * RPP3;
-                const int row = half * 64 + ml;
+            for (int b = 0; b < TM2; ++b) {
+                const int row = wave * RP + b * 16 + frow;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float v[8];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float4 t4 = *(const float4*)(stg + ml * LD3 + ec3 * 16 + 8 * g + 4 * q);
-                        const float4 bq = *(const float4*)(bias_a_s + ec3 * 20 + 8 * g + 4 * q);
-                        v[4 * q] = fmaxf(__fadd_rn(t4.x, bq.x), 0.f); v[4 * q + 1] = fmaxf(__fadd_rn(t4.y, bq.y), 0.f);
-                        v[4 * q + 2] = fmaxf(__fadd_rn(t4.z, bq.z), 0.f); v[4 * q + 3] = fmaxf(__fadd_rn(t4.w, bq.w), 0.f);
-                    }
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(__fadd_rn(acc3[g3 * 4 + 2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]), 0.f);
                     const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, srd_t, (row * NRED + ec3 * 16 + 8 * g) * 2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, srd_t, (row * NRED + g3 * 64 + fq * 16 + 8 * g) * 2, 0, 0);
                 }
             }
         }
+    }
+    if (p.dbg) {
+        __syncthreads();
+        if (tid == 0) p.dbg[blockIdx.x * 8ull + 5] = wall_clock64();
     }
 }
 #undef FAV_BAR

@@ -56,14 +56,17 @@ class TorchNet:
 
     @staticmethod
     def _conv(x, L, res=None, relu=True, keep=None, scale=1.0):
+        """conv + bias (fused by the library, fp32) + residual + ReLU + dropout, in place, one bf16 rounding.
+        `keep` is a float mask holding `scale` where the element survives and 0 where it is dropped (the
+        activation is >= 0 after the ReLU, so y * mask == where(keep, y * scale, 0) exactly)."""
         w, b, stride, pad = L
-        y = F.conv2d(x, w, None, stride, pad) + b.view(1, -1, 1, 1)
+        y = F.conv2d(x, w, b, stride, pad)
         if res is not None:
-            y = y + res
+            y.add_(res)
         if relu:
-            y = torch.relu(y)
+            y.relu_()
         if keep is not None:
-            y = torch.where(keep, y * scale, torch.zeros((), dtype=torch.float32))
+            y.mul_(keep)
         return _bf16(y)
 
     def stem(self, xn):
@@ -88,20 +91,26 @@ class TorchNet:
                 acc = acc + x[:, :, i, j]
         y = acc * float(np.float32(1.0 / (h * w)))
         if keep is not None:
-            y = torch.where(keep, y * scale, torch.zeros((), dtype=torch.float32))
+            y = y * keep
         return F.linear(_bf16(y), self.fc_w, self.fc_b)
 
     @staticmethod
     def _make_keep_nchw(seed, t, site, img_ids, shape_nchw, thr):
+        """float32 NCHW (channels-last memory) mask: dropout_scale(thr) where kept, 0 where dropped."""
         b, c, h, w = shape_nchw
         k = O.dropout_keep(seed, t, site, img_ids, h * w * c, thr).reshape(b, h, w, c)
-        return torch.from_numpy(np.ascontiguousarray(k.transpose(0, 3, 1, 2)))
+        m = torch.from_numpy(k).to(torch.float32).mul_(float(O.dropout_scale(thr)))
+        return m.permute(0, 3, 1, 2)
 
     def _keep_nchw(self, seed, t, site, img_ids, shape_nchw, thr):
         return self._cached((t, site), lambda: self._make_keep_nchw(seed, t, site, img_ids, shape_nchw, thr))
 
+    @staticmethod
+    def _make_keep_vec(seed, t, site, img_ids, n, thr):
+        return torch.from_numpy(O.dropout_keep(seed, t, site, img_ids, n, thr)).to(torch.float32).mul_(float(O.dropout_scale(thr)))
+
     def _keep_vec(self, seed, t, site, img_ids, n, thr):
-        return self._cached((t, site), lambda: torch.from_numpy(O.dropout_keep(seed, t, site, img_ids, n, thr)))
+        return self._cached((t, site), lambda: self._make_keep_vec(seed, t, site, img_ids, n, thr))
 
     @torch.no_grad()
     def forward_logits(self, xn_nhwc: np.ndarray, img_ids=None, n_samples=1, site_mask=0, p=0.0, seed=0,
@@ -152,7 +161,7 @@ class TorchNet:
             keep = None
             if site_mask >> self.nb & 1:
                 keep = self._cached(("stacked", self.nb), lambda: torch.cat(
-                    [torch.from_numpy(O.dropout_keep(seed, t, self.nb, img_ids, act.shape[1], thr)) for t in range(T)], dim=0))
+                    [self._make_keep_vec(seed, t, self.nb, img_ids, act.shape[1], thr) for t in range(T)], dim=0))
             return self.pool_fc(act, keep, scale).reshape(T, b, -1)
 
         act = self.stem(x)
@@ -173,15 +182,15 @@ class TorchNet:
         if stack_samples and first < self.nb:
             keep0 = self._cached(("stacked", first), lambda: torch.cat(
                 [self._make_keep_nchw(seed, t, first, img_ids, tuple(act.shape), thr) for t in range(n_samples)], dim=0))
-            ent = _bf16(torch.where(keep0, act.repeat(n_samples, 1, 1, 1) * scale, zero))
+            ent = _bf16(act.repeat(n_samples, 1, 1, 1).mul_(keep0))
             return run_from_stacked(npre, list(ent.split(b, dim=0))).numpy()
         for t in range(n_samples):
             if first == self.nb:
                 keep = self._keep_vec(seed, t, first, img_ids, pooled.shape[1], thr)
-                outs.append(F.linear(_bf16(torch.where(keep, pooled * scale, zero)), self.fc_w, self.fc_b))
+                outs.append(F.linear(_bf16(pooled * keep), self.fc_w, self.fc_b))
             else:
                 keep = self._keep_nchw(seed, t, first, img_ids, tuple(act.shape), thr)
-                outs.append(run_from(npre, _bf16(torch.where(keep, act * scale, zero)), t))
+                outs.append(run_from(npre, _bf16(act * keep), t))
         return torch.stack(outs).numpy()
 
 

@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def note(line):
+    """Measured values behind a tolerance, kept with the run's other outputs (gpurun_out/ is merged back)."""
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "e2e_measured.txt"), "a") as f:
+            f.write(line + "\n")
+    print(line)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 from failure_aware_vision_amd import Backend, synth  # noqa: E402
+from conftest import note  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 FRAME_SEED, NOISE_SEED, SEVERITY = 21, 3, 3
@@ -97,7 +98,7 @@ def test_production_mode_vs_independent_torch_cpu(r50_blob):
     bad = lg != ref
     second = (lg[bad] == d["second"][bad]).mean() if bad.any() else 1.0
     hist = np.histogram(gap[bad], bins=[0, 0.0025, 0.005, 0.01, 0.02, 0.05, 1.0])[0]
-    print(f"production vs torch-CPU: {n - bad.sum()} / {n} labels equal; top-2 gap histogram of the disagreements "
+    note(f"production vs torch-CPU: {n - bad.sum()} / {n} labels equal; top-2 gap histogram of the disagreements "
           f"[0, .0025, .005, .01, .02, .05, 1]: {hist.tolist()}; GPU label is torch's second choice in {second:.2f} of them; "
           f"max |dconf| {np.abs(cg - d['conf']).max():.4f}")
     assert bad.mean() <= 0.035
@@ -141,8 +142,10 @@ def test_mc_dropout_t30_fixture(r50_blob):
     l2, c2 = be.classify(x)
     l2, c2 = l2.cpu().numpy(), c2.cpu().numpy()
     bad = l2 != d["labels"]
-    assert bad.mean() <= 0.15 and np.all(d["gap"][bad] < 0.25), (bad.mean(), d["gap"][bad])
-    assert np.abs(c2 - d["conf"]).max() < 0.10
+    note(f"T=30 x 64 frames, production vs exact-mode fixture: {bad.sum()} labels differ, largest gap among them "
+         f"{d['gap'][bad].max() if bad.any() else 0:.4f}, max |dconf| {np.abs(c2 - d['conf']).max():.4f}")
+    assert bad.mean() <= 0.10 and np.all(d["gap"][bad] < 0.05), (bad.mean(), d["gap"][bad])
+    assert np.abs(c2 - d["conf"]).max() < 0.05
     be.close()
 
 
@@ -167,9 +170,10 @@ def test_ten_thousand_corrupted_frames(r50_blob):
     np.testing.assert_allclose(ce, gold_c, rtol=0, atol=3e-6)
     assert len(np.unique(gold_l)) >= 20
     bad = lf != gold_l
-    print(f"bf16 mode: {bad.sum()} of {n} labels differ from the exact-mode oracle; "
-          f"largest oracle gap among them {gap[bad].max() if bad.any() else 0:.4f}; "
-          f"max |dconf| {np.abs(cf - gold_c).max():.4f}")
-    assert bad.mean() <= 0.10 and np.all(gap[bad] < 0.30)
-    assert np.abs(cf - gold_c).max() < 0.15
+    note(f"10,000 frames, production vs exact-mode fixture: {bad.sum()} of {n} labels differ; "
+         f"largest oracle gap among them {gap[bad].max() if bad.any() else 0:.4f}; "
+         f"max |dconf| {np.abs(cf - gold_c).max():.4f}")
+    # measured: 196 of 10,000, every one with a top-2 gap below 0.019, confidence moves by at most 0.033
+    assert bad.mean() <= 0.03 and np.all(gap[bad] < 0.03)
+    assert np.abs(cf - gold_c).max() < 0.05
     exact.close(); fast.close()
