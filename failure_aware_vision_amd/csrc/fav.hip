@@ -358,8 +358,16 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     dim3 grid((unsigned)tiles);
     p.nk = p.K / BK;
     const int NS = conv_ns(BK);
-#define FAV_LAUNCH(BN_, BK_, NS_, MODE_) \
-    hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_>), grid, dim3(256), 0, s, p)
+    // FAV_CONV_EPI=0 selects the round-1 epilogue (fp32 staging through LDS) for A/B measurements
+    // measured (profiles/r2b_conv_epilogue_ab.txt): the register epilogue wins 2-4 % on the 3x3 and K >= 512 launches
+    // and loses ~3 % on the launches with a residual, so those keep the staged one.  FAV_CONV_EPI=0|1 forces.
+    static const int epi_forced = [] { const char* e = getenv("FAV_CONV_EPI"); return e ? atoi(e) : -1; }();
+    const int epi = epi_forced >= 0 ? epi_forced : (d.res ? 0 : 1);
+#define FAV_LAUNCH(BN_, BK_, NS_, MODE_)                                                                          \
+    do {                                                                                                          \
+        if (epi) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 1>), grid, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 0>), grid, dim3(256), 0, s, p);     \
+    } while (0)
 #define FAV_LAUNCH_NS(BN_, BK_, MODE_)                                                            \
     do {                                                                                          \
         if (NS == 2) FAV_LAUNCH(BN_, BK_, 2, MODE_);                                              \
@@ -371,10 +379,15 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
         if (BN == 128) { if (BK == 32) FAV_LAUNCH_NS(128, 32, MODE_); else FAV_LAUNCH_NS(128, 64, MODE_); } \
         else { if (BK == 32) FAV_LAUNCH_NS(64, 32, MODE_); else FAV_LAUNCH_NS(64, 64, MODE_); }   \
     } while (0)
+#define FAV_LAUNCH_BIG(MODE_)                                                                                     \
+    do {                                                                                                          \
+        if (epi) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 1>), grid, dim3(512), 0, s, p);    \
+        else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 0>), grid, dim3(512), 0, s, p);        \
+    } while (0)
     if (big) {
-        if (d.math_mode == FAV_MATH_BF16) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 1>), grid, dim3(512), 0, s, p);
+        if (d.math_mode == FAV_MATH_BF16) FAV_LAUNCH_BIG(0); else FAV_LAUNCH_BIG(1);
     } else if (d.math_mode == FAV_MATH_BF16) FAV_LAUNCH_MODE(0); else FAV_LAUNCH_MODE(1);
+#undef FAV_LAUNCH_BIG
 #undef FAV_LAUNCH_MODE
 #undef FAV_LAUNCH_NS
 #undef FAV_LAUNCH
@@ -389,14 +402,16 @@ struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2; };
 // FAV_TAIL_NW64=8; 128 mid channels: 8 waves (256 pixels, one block per CU).
 inline int tail_nw(int cmid) {
     static const int nw64 = [] { const char* e = getenv("FAV_TAIL_NW64"); return (e && atoi(e) == 8) ? 8 : 4; }();
-    return cmid == 64 ? nw64 : 8;
+    return cmid == 64 ? nw64 : (cmid == 128 ? 8 : 4);
 }
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
-    if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
+    if (cmid == 256) { if (has3x3 || nred != 0) return false; }     // wide conv_c alone: the expanding 1x1 of layer 3
+    else if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
     const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2, nw = tail_nw(cmid), bm = 32 * nw;
     const int patch = has3x3 ? (int)((((long long)(bm + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
-    int rega = std::max(std::max(patch, bm * 128), bm * rowb);        // patch | T2 tile | Y chunk
+    // region A: patch | T2 tile | Y chunk; without conv_b the T2 fragments come straight from global memory
+    int rega = has3x3 ? std::max(std::max(patch, bm * 128), bm * rowb) : (nred > 0 ? bm * 128 : 0);
     rega = (rega + 1023) / 1024 * 1024;
     const int tail = (cmid + 4 * cmid + nred) * 5 + 16;
     // Wc double-buffered when two blocks still fit a CU (4-wave blocks) / the block fits at all (8-wave blocks)
@@ -411,6 +426,11 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     g->wc2 = wc2;
     g->lds_bytes = rega + regb + tail;
     return g->lds_bytes <= 160 * 1024;
+}
+
+bool tail_wide() {
+    static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE"); return e ? atoi(e) : 1; }();
+    return on != 0;
 }
 
 bool tail_enabled() {
@@ -482,9 +502,11 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     if (cmid == 64) {
         if (has3x3) { if (nred == 0) FAV_TAIL_N(64, 0, true, 3); if (nred == 64) FAV_TAIL_N(64, 64, true, 3); if (nred == 128) FAV_TAIL_N(64, 128, true, 3); }
         else { if (nred == 0) FAV_TAIL_N(64, 0, false, 3); if (nred == 64) FAV_TAIL_N(64, 64, false, 3); if (nred == 128) FAV_TAIL_N(64, 128, false, 3); }
-    } else {
+    } else if (cmid == 128) {
         if (has3x3) { if (nred == 0) FAV_TAIL_W(128, 0, true, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, true, 2, 8); }
         else { if (nred == 0) FAV_TAIL_W(128, 0, false, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, false, 2, 8); }
+    } else {
+        FAV_TAIL_W(256, 0, false, 2, 4);
     }
 #undef FAV_TAIL_N
 #undef FAV_TAIL_W
@@ -700,8 +722,9 @@ fav_status build_graph(fav_handle* h) {
                 const int next_pl = (bi + 1 < A.depths[st]) ? pl : (st < 3 ? A.planes[st + 1] : 0);
                 int nred = boundary_after ? 0 : next_pl;
                 TailGeom tg;
-                const bool tail_3x3 = (s == 1);
-                bool fuse = tail_enabled() && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128);
+                const bool tail_3x3 = (s == 1) && pl <= 128;
+                if (pl > 128) nred = 0;                             // wide blocks: only the expanding 1x1 runs as a tail
+                bool fuse = tail_enabled() && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()));
                 if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {
                     nred = 0;
                     fuse = tail_geometry(pl, 0, tail_3x3, Wn, &tg);

@@ -73,8 +73,12 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_lo / mul_hi pair: the integer
+        // multiplier runs at a quarter of the vector rate, and the two calls per 64-channel chunk were half the
+        // epilogue's issue cycles
+        const unsigned long long p0 = (unsigned long long)M0 * c.x, p1 = (unsigned long long)M1 * c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -299,7 +303,13 @@ constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
     return blocks * (BM * 2 / 64) / 4;
 }
 
-template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0>
+// EPI = 1 (production): the epilogue runs in registers.  The weight rows of the B tile are staged in the order
+// tail_row_perm() gives (within every 64-row group LDS row 16a + i holds weight row 16*(i/4) + 4a + i%4), so lane
+// (pixel frow, quad fq) ends up with 16 CONSECUTIVE output channels of its pixel per group: bias, residual, ReLU /
+// GELU, Philox dropout (one call = exactly its 16 draws) and the bf16 rounding need no fp32 staging through LDS and no
+// barrier.  (Tiles with 32 columns per wave use 32-row groups and 8 channels per lane.)  The sums are unchanged - an
+// output element still meets its products in ascending k.  EPI = 0 is the round-1 epilogue through an fp32 LDS stage.
+template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1>
 __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = (BM / 64) * WN * 64;     // threads: (BM/64) x WN waves, each a 64 x BN/WN sub-tile
     constexpr int NWAVES = NT / 64;
@@ -312,7 +322,10 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int OUT_LD = BN + 4;              // fp32 staging row stride (floats)
     constexpr int OUT_BYTES = 64 * OUT_LD * 4;  // the epilogue stages 64 rows (one wave row) at a time
-    constexpr int LDS_BYTES = (NS * STAGE_BYTES > OUT_BYTES) ? NS * STAGE_BYTES : OUT_BYTES;
+    constexpr int LDS_BYTES = (EPI == 1 || NS * STAGE_BYTES > OUT_BYTES) ? NS * STAGE_BYTES : OUT_BYTES;
+    constexpr int GS = WTN >= 64 ? 64 : 32;     // EPI 1: rows per permuted group of the B tile
+    constexpr int CPL = GS / 4;                 // ... and consecutive channels a lane holds per group (16 or 8)
+    constexpr int NG = WTN / GS;                // ... groups per wave
     constexpr int AR = A_BYTES / 1024 / NWAVES, BR = B_BYTES / 1024 / NWAVES;  // LDS-DMA pieces per wave per tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BN * 5];  // + this tile's bias, 16-channel chunks 20 floats apart
 
@@ -357,6 +370,43 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     constexpr bool RES_ALL = NGROUPS * NPASS * 2 <= 8;
     constexpr int RG = RES_ALL ? NGROUPS : 1;
     u32x4_t rres[RG][NPASS][2];
+    // EPI 1: lane (frow, fq) of wave (wm, wn) finishes, for b < TM and g < NG, the CPL channels
+    // n0 + wn*WTN + g*GS + CPL*fq .. of pixel m0 + wm*64 + b*16 + frow.  Residual: all of the tile's rows before the
+    // K loop when they fit in 8 registers quads, else one pixel tile b ahead of the stores (two sets).
+    constexpr int RQ = CPL / 8;                              // 16-B quads per (b, g)
+    constexpr bool RES_ALL1 = TM * NG * RQ <= 8;
+    constexpr int RB = RES_ALL1 ? TM : 2;
+    u32x4_t rr1[RB][NG][RQ];
+    const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+    const int esz = p.out_f32 ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t srd_res1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res ? p.res + (long long)m0 * p.ldy : p.x), 0, p.res ? rows_valid * p.ldy * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_y1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.y + (long long)m0 * p.ldy * esz), 0, rows_valid * p.ldy * esz, 0x00020000);
+#define FAV_LOAD_RES1(SLOT, B)                                                                   \
+    _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_)                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < RQ; ++q_)                                        \
+            rr1[SLOT][g_][q_] = __builtin_amdgcn_raw_buffer_load_b128(                           \
+                srd_res1, ((wm * 64 + (B) * 16 + (lane & 15)) * p.ldy + n0 + wn * WTN + g_ * GS + CPL * (lane >> 4) + 8 * q_) * 2, 0, 0)
+#define FAV_RES1_LANDED(SLOT)                                                                    \
+    _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_)                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < RQ; ++q_) asm volatile("" : "+v"(rr1[SLOT][g_][q_]))
+    if (EPI == 1) {
+#pragma unroll
+        for (int b_ = 0; b_ < RB; ++b_)
+#pragma unroll
+            for (int g_ = 0; g_ < NG; ++g_)
+#pragma unroll
+                for (int q_ = 0; q_ < RQ; ++q_) rr1[b_][g_][q_] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (p.res) {
+            if (RES_ALL1) {
+#pragma unroll
+                for (int b_ = 0; b_ < TM; ++b_) FAV_LOAD_RES1(b_, b_);
+            } else {
+                FAV_LOAD_RES1(0, 0);
+            }
+        }
+    }
 #define FAV_LOAD_RES(G, HALF)                                                              \
     _Pragma("unroll") for (int pass = 0; pass < NPASS; ++pass) {                           \
         const int m = m0 + (HALF) * 64 + er + pass * RPP;                                  \
@@ -377,7 +427,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     for (int g_ = 0; g_ < RG; ++g_)
 #pragma unroll
         for (int q_ = 0; q_ < NPASS; ++q_) rres[g_][q_][0] = rres[g_][q_][1] = (u32x4_t){0u, 0u, 0u, 0u};
-    if (RES_ALL && p.res) {
+    if (EPI == 0 && RES_ALL && p.res) {
 #pragma unroll
         for (int g = 0; g < NGROUPS; ++g) FAV_LOAD_RES(g, g)
     }
@@ -428,7 +478,11 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     }
     uint32_t b_voff[BR];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)((((wave * BR + i) * PROWS + lrow) * p.K + lch * 8) * 2);
+    for (int i = 0; i < BR; ++i) {
+        int r = (wave * BR + i) * PROWS + lrow;      // LDS row of the B tile this lane fills
+        if (EPI == 1) r = (r & ~(GS - 1)) + CPL * ((r & 15) >> 2) + 4 * ((r >> 4) & (GS / 16 - 1)) + (r & 3);   // weight row it holds
+        b_voff[i] = (uint32_t)((r * p.K + lch * 8) * 2);
+    }
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)smem);
     const uint32_t lds_a = lds_base + wave_u * (AR * 1024);
@@ -551,6 +605,87 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     // barrier.  (The barrier that ended the K loop already separates the last fragment
     // reads from the first staging writes.)
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 2] = wall_clock64();
+    if (EPI == 1) {
+        // ---- epilogue in registers (see the comment above the kernel) -----------------------------------------
+        const int pr = wm * 64 + frow;                       // pixel row of b = 0 inside the tile
+        float bia[NG][CPL];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                const int c = wn * WTN + g * GS + CPL * fq + 4 * q;          // column inside the tile
+                const float4 bq = *(const float4*)((const float*)(smem + LDS_BYTES) + (c >> 4) * 20 + (c & 15));
+                bia[g][4 * q] = bq.x; bia[g][4 * q + 1] = bq.y; bia[g][4 * q + 2] = bq.z; bia[g][4 * q + 3] = bq.w;
+            }
+        if (RES_ALL1) {
+#pragma unroll
+            for (int b_ = 0; b_ < TM; ++b_) FAV_RES1_LANDED(b_);
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int slot = RES_ALL1 ? b : (b & 1);
+            if (!RES_ALL1) {
+                FAV_RES1_LANDED(b & 1);
+                if (p.res && b + 1 < TM) FAV_LOAD_RES1((b + 1) & 1, b + 1);   // one pixel tile ahead of this one's stores
+            }
+            const int ml = pr + b * 16;
+            const int m = m0 + ml;
+            uint32_t vl = 0, pix = 0;
+            if (!p.out_f32 && p.drop.site >= 0) {
+                vl = fastdiv((uint32_t)m, p.div_hwo);
+                pix = (uint32_t)m - vl * (uint32_t)p.HWo;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int n = n0 + wn * WTN + g * GS + CPL * fq;
+                uint32_t draws[4] = {~0u, ~0u, ~0u, ~0u};
+                if (!p.out_f32 && p.drop.site >= 0) {
+                    const uint32_t chunk = (uint32_t)(((long long)pix * p.Cout + n) >> 4);
+                    const uint4 w = drop_draws16(p.drop, (uint32_t)p.drop.v0 + vl, chunk);
+                    if (CPL == 16 || !(fq & 1)) { draws[0] = w.x; draws[1] = w.y; draws[2] = w.z; draws[3] = w.w; }
+                    else { draws[0] = w.z; draws[1] = w.w; }    // 8 channels per lane: the odd quad owns draws 8..15
+                }
+#pragma unroll
+                for (int h8 = 0; h8 < CPL / 8; ++h8) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc[g * (GS / 16) + 2 * h8 + (k >> 2)][b][k & 3], bia[g][8 * h8 + k]);
+                    if (p.res) {
+                        const uint32_t rw[4] = {rr1[slot][g][h8][0], rr1[slot][g][h8][1], rr1[slot][g][h8][2], rr1[slot][g][h8][3]};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] = __fadd_rn(v[2 * k], bf16_bits_to_f32(rw[k] & 0xFFFFu));
+                            v[2 * k + 1] = __fadd_rn(v[2 * k + 1], bf16_bits_to_f32(rw[k] >> 16));
+                        }
+                    }
+                    if (p.relu == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                    } else if (p.relu == 2) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = fav_gelu(v[k]);
+                    }
+                    if (p.out_f32) {
+                        if (m < p.M) {
+                            float* yo = (float*)p.y + (long long)m * p.ldy + n + 8 * h8;
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)
+                                if (n + 8 * h8 + 4 * q < p.Cout)
+                                    *(float4*)(yo + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                        }
+                    } else {
+                        if (p.drop.site >= 0) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = FAV_DROP_APPLY(v[k], draws, 8 * h8 + k, p.drop);
+                        }
+                        const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        // unconditional: rows beyond M fail the descriptor's range check (the store count stays a constant)
+                        __builtin_amdgcn_raw_buffer_store_b128(o, srd_y1, (ml * p.ldy + n + 8 * h8) * 2, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
     float* outs = (float*)smem;
     FAV_RES_LANDED();
 #pragma unroll
@@ -632,6 +767,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
             }
         }
     }
+    }
     if (p.dbg) {
         __syncthreads();
         if (tid == 0) p.dbg[blockIdx.x * 4ull + 3] = wall_clock64();
@@ -641,6 +777,8 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
 #undef FAV_STAGE
 #undef FAV_LOAD_RES
 #undef FAV_RES_LANDED
+#undef FAV_LOAD_RES1
+#undef FAV_RES1_LANDED
 
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with the input staged ONCE per tile.
@@ -966,6 +1104,13 @@ __device__ __forceinline__ int tail_row_perm(int r) {
     return g + 16 * (i >> 2) + 4 * a + (i & 3);
 }
 
+// XOR applied to the 16-B chunk index of an activation row of CPR chunks (128, 256 or 512 B), chosen so that the 16
+// lanes one ds_read_b128 group serves - 8 rows with quad f and the other 8 with quad f + 1 - hit 16 different slots
+template <int CPR>
+__device__ __forceinline__ int tail_sw(int row) {
+    return CPR == 8 ? (row & 7) : (CPR == 16 ? ((row & 7) | ((row & 1) << 3)) : (row & 15));
+}
+
 template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
     constexpr int COUT = 4 * CMID;
@@ -994,14 +1139,17 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     constexpr int WC_PIECES = WC_BYTES / 1024, WA_PIECES = WA_BYTES / 1024;
     constexpr int WC_PW = (WC_PIECES + NW - 1) / NW, WA_PW = (WA_PIECES + NW - 1) / NW;   // pieces per wave (the last may be skipped)
     static_assert(BR >= 1 && TN1 >= 1 && TM2 >= 1 && WC_PIECES % NW == 0 && (NRED == 0 || WA_PIECES % NW == 0), "tile shape");
+    static_assert(!HAS3X3 || (NKT % NS == 0 && WC_BYTES <= SLOT), "Wc buffer 0 = ring slot 0, free during the last NS - 1 steps");
+    constexpr bool WA0_EARLY = !HAS3X3 || WCN * WC_BYTES + WA_BYTES >= RING;   // chunk 0's Wa buffer lies beyond the P1 ring
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
     // [region A | region B: weight ring (P1) / Wc x2, Wa x2 (P2) | biases (16-channel chunks 20 floats apart) | 16 zero bytes]
     unsigned char* const ych = tsm;                                // P2: Y chunk [BM][64] bf16, chunk ^= row & 7
     unsigned char* const regb = tsm + p.rega_bytes;
-    float* const bias_b_s = (float*)(regb + REGB);
+    const int bias_off = p.rega_bytes + REGB;
+    float* const bias_b_s = (float*)(tsm + bias_off);
     float* const bias_c_s = bias_b_s + (CMID / 16) * 20;
     float* const bias_a_s = bias_c_s + (COUT / 16) * 20;
-    const uint32_t zero_off = (uint32_t)(p.rega_bytes + REGB + (CMID + COUT + NRED) * 5);
+    const uint32_t zero_off = (uint32_t)(bias_off + (CMID + COUT + NRED) * 5);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN1, wn = wave % WN1;
@@ -1040,17 +1188,18 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                       __builtin_amdgcn_readfirstlane(lds_regb + (uint32_t)(((J) % WCN) * WC_BYTES + pc * 1024)));  \
         }                                                                                                        \
     } while (0)
-// Wa chunk J (NRED rows x 64 k) -> buffer J & 1
+// Wa chunk J (NRED rows x 64 k) -> buffer (J + 1) & 1: chunk 0's lies beyond the P1 weight ring, so it is requested in P0
 #define FAV_T_STAGE_WA(J)                                                                                        \
     do {                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < WA_PW; ++i) {                                                      \
             const int pc = wave_u + i * NW;                                                                      \
             lds_dma16(srd_wa, (uint32_t)((tail_row_perm(pc * 8 + wrow) * COUT + wch * 8) * 2), (uint32_t)((J) * 128), \
-                      __builtin_amdgcn_readfirstlane(lds_regb + (uint32_t)(WCN * WC_BYTES + ((J) & 1) * WA_BYTES + pc * 1024))); \
+                      __builtin_amdgcn_readfirstlane(lds_regb + (uint32_t)(WCN * WC_BYTES + (((J) + 1) & 1) * WA_BYTES + pc * 1024))); \
         }                                                                                                        \
     } while (0)
 
     const int W = p.W;
+    if (NRED > 0 && WA0_EARLY) FAV_T_STAGE_WA(0);   // oldest request of the block (its buffer is not part of the P1 ring)
     if (HAS3X3) {
         f32x4_t acc[TN1][TM];
         // ---- patch: flattened input pixels [m0 - W - 1, m0 + BM + W + 1), all CMID channels --------------------
@@ -1062,7 +1211,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             const int lrow = lane / CPR, lslot = lane % CPR;
             for (int j = wave_u; j < npieces; j += NW) {
                 const int q = j * PROWS + lrow;
-                const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
+                const int sw = tail_sw<CPR>(q);
                 const long long g = g0 + q;
                 const bool ok = g >= 0 && g < (long long)p.M;
                 const uint32_t voff = ok ? (uint32_t)((g - gbase) * ROWB + ((lslot ^ sw) << 4)) : OOB;
@@ -1110,12 +1259,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         int tap = 0, cb = 0, tapoff = 0, tr = 0, ts = 0;
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt + NS - 1 < NKT) FAV_T_HSTAGE(nxt, kt + NS - 1);
+            else if (kt + NS - 1 == NKT) FAV_T_STAGE_WC(0);   // ring slot NKT % NS = 0 is free: conv_c's first weights ride under the last steps
             const unsigned char* Bs = regb + cur * SLOT;
             uint32_t a_addr[TM];
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int q = wm * 64 + b * 16 + frow + tapoff;
-                const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
+                const int sw = tail_sw<CPR>(q);
                 const uint32_t ad = (uint32_t)q * ROWB + (uint32_t)(((cb * 8 + fq) ^ sw) << 4);
                 a_addr[b] = ((tapmask[b] >> tap) & 1u) ? ad : zero_off;
             }
@@ -1148,17 +1298,16 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 if (++ts == 3) { ts = 0; ++tr; }
                 tapoff = tr * W + ts;
             }
+            // the next step's K tile has landed; behind it only younger ring tiles / the Wc pieces may still be in flight
             if (kt + NS - 1 < NKT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (kt + 1 < NKT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC_PW + (NS - 3) * BR) : "memory");
             __syncthreads();
             cur = (cur + 1 == NS) ? 0 : cur + 1;
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
 #undef FAV_T_HSTAGE
+        if (NRED > 0 && !WA0_EARLY) FAV_T_STAGE_WA(0);
         if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 2] = wall_clock64();
-        // the weight ring is free: request the first chunk's weights (region B is theirs from here on)
-        FAV_T_STAGE_WC(0);
-        if (NRED > 0) FAV_T_STAGE_WA(0);
         // ---- P1e: T2 = bf16(relu(acc + bias_b)) -> LDS [BM][CMID], operand layout (every wave is past the patch) ----
 #pragma unroll
         for (int a = 0; a < TN1; ++a)
@@ -1169,36 +1318,39 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 const float4 bq = *(const float4*)(bias_b_s + (c0 >> 4) * 20 + (c0 & 15));
                 const float v0 = fmaxf(__fadd_rn(acc[a][b][0], bq.x), 0.f), v1 = fmaxf(__fadd_rn(acc[a][b][1], bq.y), 0.f);
                 const float v2 = fmaxf(__fadd_rn(acc[a][b][2], bq.z), 0.f), v3 = fmaxf(__fadd_rn(acc[a][b][3], bq.w), 0.f);
-                const int sw = (CPR == 8) ? (row & 7) : ((row & 7) | ((row & 1) << 3));
+                const int sw = tail_sw<CPR>(row);
                 *(uint2*)(tsm + row * ROWB + (((c0 >> 3) ^ sw) << 4) + ((c0 >> 2) & 1) * 8) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
             }
-    } else {
-        // ---- conv_c alone: its input tile [BM][CMID] straight into the operand layout -------------------------
-        FAV_T_STAGE_WC(0);
-        if (NRED > 0) FAV_T_STAGE_WA(0);
-        const __amdgpu_buffer_rsrc_t srd_a =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + (long long)m0 * CMID), 0, rows_valid * ROWB, 0x00020000);
-        const int lrow = lane / CPR, lslot = lane % CPR;
-#pragma unroll
-        for (int i = 0; i < BM * ROWB / 1024 / NW; ++i) {
-            const int j = wave_u + i * NW;
-            const int q = j * PROWS + lrow;
-            const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
-            lds_dma16(srd_a, (uint32_t)(q * ROWB + ((lslot ^ sw) << 4)), 0u, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)j * 1024u));
-        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // T2 tile (DMA path) and the first chunk's weights
-    __syncthreads();
     // wave w owns pixel rows [w*RP, w*RP + RP): their T2 fragments (all CMID k) live in registers from here on
     uint4 t2f[TM2][KS2];
+    if (HAS3X3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights
+        __syncthreads();                                      // T2 tile complete, weight pieces of every wave visible
 #pragma unroll
-    for (int b = 0; b < TM2; ++b) {
-        const int row = wave * RP + b * 16 + frow;
-        const int sw = (CPR == 8) ? (row & 7) : ((row & 7) | ((row & 1) << 3));
+        for (int b = 0; b < TM2; ++b) {
+            const int row = wave * RP + b * 16 + frow;
+            const int sw = tail_sw<CPR>(row);
 #pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) t2f[b][ks] = *(const uint4*)(tsm + row * ROWB + (((ks * 4 + fq) ^ sw) << 4));
+            for (int ks = 0; ks < KS2; ++ks) t2f[b][ks] = *(const uint4*)(tsm + row * ROWB + (((ks * 4 + fq) ^ sw) << 4));
+        }
+        __syncthreads();                                      // region A becomes the Y-chunk image
+    } else {
+        // ---- conv_c alone: every wave reads the fragments of ITS rows straight from global memory (each byte of the
+        //      tile is needed by one wave only, so an LDS round trip and its two barriers would buy nothing) ----------
+        FAV_T_STAGE_WC(0);
+        const __amdgpu_buffer_rsrc_t srd_a =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + (long long)m0 * CMID), 0, rows_valid * ROWB, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < TM2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(srd_a, (wave * RP + b * 16 + frow) * ROWB + (ks * 4 + fq) * 16, 0, 0);
+                t2f[b][ks] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights (and the fragments)
+        __syncthreads();
     }
-    __syncthreads();                                      // region A becomes the Y-chunk image
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 3] = wall_clock64();
 
     // ---- P2 ---------------------------------------------------------------------------------------------------
@@ -1236,7 +1388,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 #pragma unroll
     for (int j = 0; j < NCHUNK; ++j) {
         const unsigned char* const wcb = regb + (j % WCN) * WC_BYTES;
-        const unsigned char* const wab = regb + WCN * WC_BYTES + (j & 1) * WA_BYTES;
+        const unsigned char* const wab = regb + WCN * WC_BYTES + ((j + 1) & 1) * WA_BYTES;
         // residual of THIS chunk has landed; then the requests of the NEXT chunk (the other weight buffers: every
         // wave is past chunk j-1, the barrier at its end says so)
 #pragma unroll

@@ -54,6 +54,8 @@ CASES = [
     (128, 128, False, 28, 28, 3),   # the stride-2 block: its 3x3 stays a separate launch
     (64, 64, False, 14, 10, 5),
     (128, 128, True, 9, 11, 7),
+    (256, 0, False, 14, 14, 11),    # layer 3's expanding 1x1 alone (wide tail: weight buffers reuse the T2 region); M = 2156
+    (256, 0, False, 7, 9, 3),
 ]
 
 

@@ -12,6 +12,7 @@ SHAPES = [  # name, H, Cmid, Nred, has3x3
     ("L1 tail 3x3+c+a 64/256->64", 56, 64, 64, 1), ("L1->L2 tail 64/256->128", 56, 64, 128, 1),
     ("L2 tail no3x3 128/512->128", 28, 128, 128, 0), ("L2 tail 3x3+c+a 128/512->128", 28, 128, 128, 1),
     ("L2 last tail 3x3+c 128/512", 28, 128, 0, 1),
+    ("L3 conv_c alone 256/1024", 14, 256, 0, 0),
 ]
 
 
