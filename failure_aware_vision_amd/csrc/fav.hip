@@ -397,7 +397,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 
 
 // ---- bottleneck tail (conv_b 3x3 -> conv_c 1x1 + residual + dropout -> next block's conv_a 1x1), one launch ----
-struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2; };
+struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2, rp; };
 // Waves per block (pixels per block = 32 * waves).  64 mid channels: 4 waves (128 pixels, two blocks per CU) unless
 // FAV_TAIL_NW64=8; 128 mid channels: 8 waves (256 pixels, one block per CU).
 inline int tail_nw(int cmid) {
@@ -406,9 +406,11 @@ inline int tail_nw(int cmid) {
 }
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
-    if (cmid == 256) { if (has3x3 || nred != 0) return false; }     // wide conv_c alone: the expanding 1x1 of layer 3
+    // 256 mid channels (layer 3): the expanding 1x1 alone, or with the next block's reduce (then 8 waves x 16 rows)
+    if (cmid == 256) { if (has3x3 || !(nred == 0 || nred == 256)) return false; }
     else if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
-    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2, nw = tail_nw(cmid), bm = 32 * nw;
+    const int rp = (cmid == 256 && nred == 256) ? 16 : 32;
+    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2, nw = (cmid == 256 && nred == 256) ? 8 : tail_nw(cmid), bm = rp * nw;
     const int patch = has3x3 ? (int)((((long long)(bm + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
     // region A: patch | T2 tile | Y chunk; without conv_b the T2 fragments come straight from global memory
     int rega = has3x3 ? std::max(std::max(patch, bm * 128), bm * rowb) : (nred > 0 ? bm * 128 : 0);
@@ -423,6 +425,7 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     g->patch_bytes = patch;
     g->rega_bytes = rega;
     g->nw = nw;
+    g->rp = rp;
     g->wc2 = wc2;
     g->lds_bytes = rega + regb + tail;
     return g->lds_bytes <= 160 * 1024;
@@ -430,6 +433,13 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
 
 bool tail_wide() {
     static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
+// 256 mid channels + the next block's reduce in one launch (8 waves x 16 rows, one weight fragment read per MFMA):
+// measured 3.01 ms against 1.77 ms (expand alone as a tail) + 0.95 ms (generic reduce) -> off by default
+bool tail_wide_reduce() {
+    static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE_REDUCE"); return e ? atoi(e) : 0; }();
     return on != 0;
 }
 
@@ -459,7 +469,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
     const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
-    const int bm = 32 * g.nw;
+    const int bm = g.rp * g.nw;
     const long long nblocks = (M + bm - 1) / bm;
     dim3 grid((unsigned)nblocks);
     p.dbg = nullptr;
@@ -505,8 +515,20 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     } else if (cmid == 128) {
         if (has3x3) { if (nred == 0) FAV_TAIL_W(128, 0, true, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, true, 2, 8); }
         else { if (nred == 0) FAV_TAIL_W(128, 0, false, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, false, 2, 8); }
-    } else {
+    } else if (nred == 0) {
         FAV_TAIL_W(256, 0, false, 2, 4);
+    } else {
+        static DeviceFlags attr_set;
+        if (!attr_set.test_current()) {
+            if (hipFuncSetAttribute((const void*)bottleneck_tail_kernel<256, 256, false, 2, 8, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)bottleneck_tail_kernel<256, 256, false, 2, 8, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return "bottleneck tail: cannot reserve LDS";
+            attr_set.set_current();
+        }
+        if (g.wc2) hipLaunchKernelGGL((bottleneck_tail_kernel<256, 256, false, 2, 8, true, 16>), grid, dim3(512), g.lds_bytes, s, p, g.patch_bytes);
+        else hipLaunchKernelGGL((bottleneck_tail_kernel<256, 256, false, 2, 8, false, 16>), grid, dim3(512), g.lds_bytes, s, p, g.patch_bytes);
+        dbg_report();
+        return nullptr;
     }
 #undef FAV_TAIL_N
 #undef FAV_TAIL_W
@@ -723,7 +745,7 @@ fav_status build_graph(fav_handle* h) {
                 int nred = boundary_after ? 0 : next_pl;
                 TailGeom tg;
                 const bool tail_3x3 = (s == 1) && pl <= 128;
-                if (pl > 128) nred = 0;                             // wide blocks: only the expanding 1x1 runs as a tail
+                if (pl > 128 && (nred != pl || !tail_wide_reduce())) nred = 0;   // wide blocks: the expanding 1x1 (+ the next reduce inside a stage)
                 bool fuse = tail_enabled() && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()));
                 if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {
                     nred = 0;

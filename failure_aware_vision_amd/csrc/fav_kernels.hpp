@@ -1111,10 +1111,11 @@ __device__ __forceinline__ int tail_sw(int row) {
     return CPR == 8 ? (row & 7) : (CPR == 16 ? ((row & 7) | ((row & 1) << 3)) : (row & 15));
 }
 
-template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2>
+template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
     constexpr int COUT = 4 * CMID;
-    constexpr int BM = 32 * NW, NT = NW * 64;      // every wave owns 32 pixel rows in P2
+    constexpr int BM = RP * NW, NT = NW * 64;      // every wave owns RP pixel rows in P2 (16 only without conv_b)
+    static_assert(RP == 32 || (RP == 16 && !HAS3X3), "rows per wave");
     constexpr int ROWB = CMID * 2;               // bytes per pixel of t1 / T2
     constexpr int CPR = ROWB / 16;               // 16-B chunks per pixel (8 or 16)
     constexpr int PROWS = 1024 / ROWB;           // pixels per 1-KiB LDS-DMA piece
@@ -1127,7 +1128,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     constexpr int BR = SLOT / 1024 / NW;         // LDS-DMA pieces per wave per K tile of Wb
     constexpr int NCHUNK = COUT / 64;
     constexpr int KS2 = CMID / 32;               // 32-deep k steps of conv_c
-    constexpr int RP = BM / NW;                  // pixel rows a wave owns in P2
     constexpr int TM2 = RP / 16;
     constexpr int G3 = NRED / 64;                // 64-channel groups of conv_a's output
     constexpr int WC_BYTES = 64 * ROWB;          // Wc chunk: 64 rows x CMID k, as CB sub tiles of 64 x 64

@@ -56,6 +56,8 @@ CASES = [
     (128, 128, True, 9, 11, 7),
     (256, 0, False, 14, 14, 11),    # layer 3's expanding 1x1 alone (wide tail: weight buffers reuse the T2 region); M = 2156
     (256, 0, False, 7, 9, 3),
+    (256, 256, False, 14, 14, 11),  # layer 3 inner boundary: expand + the next block's reduce, 8 waves x 16 rows
+    (256, 256, False, 5, 7, 9),
 ]
 
 
