@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfav_hip.so")
+LIB_PATH = os.environ.get("FAV_LIB_PATH") or os.path.join(_HERE, "lib", "libfav_hip.so")   # FAV_LIB_PATH: A/B of two builds
 
 FAV_OK = 0
 STATUS_NAMES = {0: "FAV_OK", 1: "FAV_ERR_INVALID_ARG", 2: "FAV_ERR_BAD_BLOB", 3: "FAV_ERR_NO_WEIGHTS",

@@ -474,25 +474,29 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     dim3 grid((unsigned)nblocks);
     p.dbg = nullptr;
     static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
-    if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)nblocks * 64); (void)hipMemset(p.dbg, 0, (size_t)nblocks * 64); }
+    if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)nblocks * 128); (void)hipMemset(p.dbg, 0, (size_t)nblocks * 128); }
     auto dbg_report = [&]() {
         if (!p.dbg) return;
         (void)hipStreamSynchronize(s);
-        std::vector<unsigned long long> t((size_t)nblocks * 8);
+        std::vector<unsigned long long> t((size_t)nblocks * 16);
         (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(p.dbg);
         unsigned long long lo = ~0ull, hi = 0;
         double ph[5] = {0, 0, 0, 0, 0};
+        double cy[5] = {0, 0, 0, 0, 0};   // chunk 1 of wave 0, shader clocks: step A | epilogue | step C | DMA wait | barrier
         for (long long i = 0; i < nblocks; ++i) {
-            lo = std::min(lo, t[i * 8]); hi = std::max(hi, t[i * 8 + 5]);
-            unsigned long long prev = t[i * 8];
-            for (int j = 0; j < 5; ++j) { const unsigned long long c = t[i * 8 + j + 1] ? t[i * 8 + j + 1] : prev; ph[j] += (double)(c - prev); prev = c; }
+            lo = std::min(lo, t[i * 16]); hi = std::max(hi, t[i * 16 + 5]);
+            unsigned long long prev = t[i * 16];
+            for (int j = 0; j < 5; ++j) { const unsigned long long c = t[i * 16 + j + 1] ? t[i * 16 + j + 1] : prev; ph[j] += (double)(c - prev); prev = c; }
+            for (int j = 0; j < 5; ++j) cy[j] += (double)(t[i * 16 + 7 + j] - t[i * 16 + 6 + j]);
         }
         const double span = (double)(hi - lo), life = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
         fprintf(stderr, "[tail dbg] blocks %lld x %d px, Cmid %d Nred %d 3x3 %d: span %.1f us; per block: patch wait %.2f us, 3x3 loop %.2f us, "
                         "T2 + first weights %.2f us, chunks %.2f us, tail %.2f us; resident blocks/CU %.2f\n", nblocks, bm, cmid, nred, (int)has3x3,
                 span / 100.0, ph[0] / nblocks / 100.0, ph[1] / nblocks / 100.0, ph[2] / nblocks / 100.0, ph[3] / nblocks / 100.0,
                 ph[4] / nblocks / 100.0, life / span / 256.0);
+        fprintf(stderr, "[tail dbg]   chunk 1, wave 0, shader clocks: step A %.0f, epilogue %.0f, step C %.0f, DMA wait %.0f, barrier %.0f\n",
+                cy[0] / nblocks, cy[1] / nblocks, cy[2] / nblocks, cy[3] / nblocks, cy[4] / nblocks);
     };
 #define FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, WC2_)                                                                   \
     do {                                                                                                              \

@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     }
     const int m0 = tile * BM;
     const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull] = wall_clock64();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull] = wall_clock64();
 
     // ---- P0: biases (plain loads, issued before any DMA), descriptors, the first requests -----------------
     if (HAS3X3) for (int i = tid; i < CMID; i += NT) bias_b_s[(i >> 4) * 20 + (i & 15)] = p.bias_b[i];
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
         __syncthreads();
-        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 1] = wall_clock64();
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
         int cur = 0, nxt = NS - 1;
         int tap = 0, cb = 0, tapoff = 0, tr = 0, ts = 0;
         for (int kt = 0; kt < NKT; ++kt) {
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         }
 #undef FAV_T_HSTAGE
         if (NRED > 0 && !WA0_EARLY) FAV_T_STAGE_WA(0);
-        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 2] = wall_clock64();
+        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 2] = wall_clock64();
         // ---- P1e: T2 = bf16(relu(acc + bias_b)) -> LDS [BM][CMID], operand layout (every wave is past the patch) ----
 #pragma unroll
         for (int a = 0; a < TN1; ++a)
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights (and the fragments)
         __syncthreads();
     }
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 3] = wall_clock64();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 3] = wall_clock64();
 
     // ---- P2 ---------------------------------------------------------------------------------------------------
     // lane (frow, fq) finishes channels 64j + 16fq .. + 15 of pixel rows wave*RP + b*16 + frow
@@ -1402,6 +1402,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             if (NRED > 0) FAV_T_STAGE_WA(j + 1);
             FAV_T_LOAD_RES(j + 1)
         }
+        if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 6] = __builtin_amdgcn_s_memtime();
         // -- A: acc2 = T2 x Wc[j]^T : RP pixels x 64 channels
         f32x4_t acc2[4][TM2];
 #pragma unroll
@@ -1426,6 +1427,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                     acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc2[a][b], 0, 0, 0);
                 }
         }
+        if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(acc2[3][TM2 - 1])); p.dbg[blockIdx.x * 16ull + 7] = __builtin_amdgcn_s_memtime(); }
         if (!WC2 && j + 1 < NCHUNK) {      // single Wc buffer: every wave has read Wc[j], the next chunk's may overwrite it
             FAV_BAR();
             FAV_T_STAGE_WC(j + 1);
@@ -1471,6 +1473,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 }
             }
         }
+        if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 8] = __builtin_amdgcn_s_memtime();
         // -- C: acc3 += Ychunk (this wave's own rows: its LDS writes are in order, no barrier) x Wa[:, 64j .. 64j+63]^T
         if constexpr (NRED > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1496,20 +1499,23 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 }
             }
         }
+        if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(acc3[NA3 - 1][TM2 - 1])); p.dbg[blockIdx.x * 16ull + 9] = __builtin_amdgcn_s_memtime(); }
         // the next chunk's weight pieces of this wave have landed (its residual loads and this chunk's stores stay in
         // flight), then the barrier publishes every wave's pieces and retires this chunk's reads of the current buffers
         if (j + 1 < NCHUNK) {
             // WC2: the youngest operations are the next residual loads and this chunk's stores; otherwise the Wc pieces
             // were issued after the residual loads, so only the stores may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC2 ? 4 * TM2 : 2 * TM2) : "memory");
+            if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 10] = __builtin_amdgcn_s_memtime();
             FAV_BAR();
+            if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 11] = __builtin_amdgcn_s_memtime();
         }
     }
 #undef FAV_T_LOAD_RES
 #undef FAV_T_STAGE_WC
 #undef FAV_T_STAGE_WA
 
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 8ull + 4] = wall_clock64();
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 4] = wall_clock64();
     // ---- P3: t1' = bf16(relu(acc3 + bias_a)): lane holds channels 64*g3 + 16fq .. + 15 of its pixel rows ----------
     if constexpr (NRED > 0) {
         const __amdgpu_buffer_rsrc_t srd_t =
@@ -1538,7 +1544,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     }
     if (p.dbg) {
         __syncthreads();
-        if (tid == 0) p.dbg[blockIdx.x * 8ull + 5] = wall_clock64();
+        if (tid == 0) p.dbg[blockIdx.x * 16ull + 5] = wall_clock64();
     }
 }
 #undef FAV_BAR
