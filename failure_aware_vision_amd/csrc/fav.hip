@@ -252,9 +252,50 @@ bool conv_big(int kh, int kw, long long M, int cout_pad, int K, bool has_res) {
     return kh * kw > 1 ? !has_res : K >= 512;
 }
 
+// ---- projection shortcut (1x1 / stride s, 256 -> 512, no residual, no ReLU) on the row-owning structure of the tail
+//      kernel: every wave gathers the fragments of its 32 output pixels straight from global memory (a strided gather
+//      costs nothing there), the 512 output channels stream through as 8 weight chunks, register epilogue.  Measured
+//      against the generic kernel on layer 2's shortcut (56x56x256 -> 28x28x512): see profiles/r2e_*.  FAV_PROJ=0 disables.
+bool proj_enabled() {
+    static const int on = [] { const char* e = getenv("FAV_PROJ"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
+bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
+    if (!proj_enabled() || d.kh != 1 || d.kw != 1 || d.pad != 0 || d.Cin != 256 || d.Cout != 512 || d.res || d.drop.site >= 0 || d.out_f32 ||
+        d.relu != 0 || d.math_mode != FAV_MATH_BF16 || (d.stride != 1 && d.stride != 2)) return false;
+    const int Ho = conv_out(d.H, 1, d.stride, 0), Wo = conv_out(d.W, 1, d.stride, 0);
+    const long long M = (long long)d.n_frames * Ho * Wo;
+    if (M < 4096 || M > 0x7fffffffLL || (long long)d.H * d.W * 512 * 4 >= 0x40000000LL) return false;
+    TailParams p;
+    memset(&p, 0, sizeof p);
+    p.t1 = (const uint16_t*)d.x; p.wc = (const uint16_t*)d.w; p.bias_c = d.bias; p.y = (uint16_t*)d.y;
+    p.H = Ho; p.W = Wo; p.HW = Ho * Wo; p.M = (int)M;
+    p.in_W = d.W; p.in_HW = d.H * d.W; p.in_stride = d.stride;
+    p.rega_bytes = 0;
+    p.drop = make_drop(nullptr);
+    p.div_hw = fastdiv_make((uint32_t)p.HW);
+    p.div_w = fastdiv_make((uint32_t)Wo);
+    p.dbg = nullptr;
+    const int lds = 2 * 64 * 512 + (256 + 512) * 5 + 16;
+    auto kern = bottleneck_tail_kernel<256, 0, false, 2, 4, true, 32, 512, false, false>;
+    static DeviceFlags attr_set;
+    if (!attr_set.test_current()) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set.set_current();
+    }
+    const double flops = 2.0 * (double)M * 256.0 * 512.0;
+    const double bytes = 2.0 * ((double)M * (256 + 512) + 256.0 * 512.0);
+    Prof pr(h, s, FAV_K_CONV, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), lds, s, p, 0);
+    return true;
+}
+
+
 const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int ldy, hipStream_t s) {
     if (d.Cin % 64 != 0) return "conv: Cin must be a multiple of 64";
     if (cout_pad % 64 != 0) return "conv: padded Cout must be a multiple of 64";
+    if (cout_pad == d.Cout && ldy == d.Cout && launch_proj(h, d, s)) return nullptr;
     ConvParams p;
     p.x = (const uint16_t*)d.x; p.w = (const uint16_t*)d.w; p.bias = d.bias; p.res = (const uint16_t*)d.res; p.y = d.y;
     p.H = d.H; p.W = d.W; p.Cin = d.Cin;
@@ -360,9 +401,10 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const int NS = conv_ns(BK);
     // FAV_CONV_EPI=0 selects the round-1 epilogue (fp32 staging through LDS) for A/B measurements
     // measured (profiles/r2b_conv_epilogue_ab.txt): the register epilogue wins 2-4 % on the 3x3 and K >= 512 launches
-    // and loses ~3 % on the launches with a residual, so those keep the staged one.  FAV_CONV_EPI=0|1 forces.
+    // (also with a residual on the 256 x 256 tile: layer 4's expand 1.24 vs 1.29 ms) and loses ~3 % on the 128-row
+    // tiles with a residual, so those keep the staged one.  FAV_CONV_EPI=0|1 forces.
     static const int epi_forced = [] { const char* e = getenv("FAV_CONV_EPI"); return e ? atoi(e) : -1; }();
-    const int epi = epi_forced >= 0 ? epi_forced : (d.res ? 0 : 1);
+    const int epi = epi_forced >= 0 ? epi_forced : ((d.res && !big) ? 0 : 1);
 #define FAV_LAUNCH(BN_, BK_, NS_, MODE_)                                                                          \
     do {                                                                                                          \
         if (epi) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 1>), grid, dim3(256), 0, s, p); \
@@ -398,12 +440,10 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 
 // ---- bottleneck tail (conv_b 3x3 -> conv_c 1x1 + residual + dropout -> next block's conv_a 1x1), one launch ----
 struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2, rp; };
-// Waves per block (pixels per block = 32 * waves).  64 mid channels: 4 waves (128 pixels, two blocks per CU) unless
-// FAV_TAIL_NW64=8; 128 mid channels: 8 waves (256 pixels, one block per CU).
-inline int tail_nw(int cmid) {
-    static const int nw64 = [] { const char* e = getenv("FAV_TAIL_NW64"); return (e && atoi(e) == 8) ? 8 : 4; }();
-    return cmid == 64 ? nw64 : (cmid == 128 ? 8 : 4);
-}
+// Waves per block (pixels per block = 32 * waves).  64 mid channels: 4 waves (128 pixels, two blocks per CU; an 8-wave
+// / 256-pixel variant measured the same, profiles/r2a_tail_bench.txt); 128 mid channels: 8 waves (256 pixels, one block
+// per CU); 256 (conv_c alone): 4 waves, two blocks per CU.
+inline int tail_nw(int cmid) { return cmid == 128 ? 8 : 4; }
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     // 256 mid channels (layer 3): the expanding 1x1 alone, or with the next block's reduce (then 8 waves x 16 rows)
@@ -460,6 +500,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     p.wc = (const uint16_t*)d.wc; p.bias_c = d.bias_c; p.res = (const uint16_t*)d.res; p.y = (uint16_t*)d.y;
     p.wa = (const uint16_t*)d.wa; p.bias_a = d.bias_a; p.t1n = (uint16_t*)d.t1n;
     p.H = d.H; p.W = d.W; p.HW = d.H * d.W; p.M = (int)M;
+    p.in_W = d.W; p.in_HW = p.HW; p.in_stride = 1;
     p.rega_bytes = g.rega_bytes;
     p.drop = make_drop(&d.drop);
     p.div_hw = fastdiv_make((uint32_t)p.HW);
@@ -512,7 +553,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
         return nullptr;                                                                                               \
     } while (0)
 #define FAV_TAIL_W(CMID_, NRED_, H3_, NS_, NW_) do { if (g.wc2) FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, true); else FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, false); } while (0)
-#define FAV_TAIL_N(CMID_, NRED_, H3_, NS_) do { if (g.nw == 4) FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 4); else FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 8); } while (0)
+#define FAV_TAIL_N(CMID_, NRED_, H3_, NS_) FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 4)
     if (cmid == 64) {
         if (has3x3) { if (nred == 0) FAV_TAIL_N(64, 0, true, 3); if (nred == 64) FAV_TAIL_N(64, 64, true, 3); if (nred == 128) FAV_TAIL_N(64, 128, true, 3); }
         else { if (nred == 0) FAV_TAIL_N(64, 0, false, 3); if (nred == 64) FAV_TAIL_N(64, 64, false, 3); if (nred == 128) FAV_TAIL_N(64, 128, false, 3); }

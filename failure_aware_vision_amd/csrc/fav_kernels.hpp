@@ -1083,7 +1083,8 @@ struct TailParams {
     uint16_t* y;              // [M][COUT]
     const uint16_t* wa; const float* bias_a;     // [NRED][COUT]
     uint16_t* t1n;            // [M][NRED]
-    int H, W, HW, M;
+    int H, W, HW, M;           // OUTPUT frame geometry (= input geometry unless in_stride > 1)
+    int in_W, in_HW, in_stride; // conv_c alone as a strided 1x1 (a downsample convolution): input row pitch, frame size, stride
     int rega_bytes;           // LDS region A: patch | T2 tile | Y chunk
     DropParams drop;
     FastDiv div_hw, div_w;
@@ -1111,9 +1112,12 @@ __device__ __forceinline__ int tail_sw(int row) {
     return CPR == 8 ? (row & 7) : (CPR == 16 ? ((row & 7) | ((row & 1) << 3)) : (row & 15));
 }
 
-template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32>
+// COUT_ = 0: the bottleneck's 4*CMID.  HAS_RES / RELU = false and in_stride = 2 turn conv_c alone into the projection
+// shortcut of a stage's first block (1x1 / 2, no residual, no ReLU, no dropout).
+template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32, int COUT_ = 0, bool HAS_RES = true, bool RELU = true>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
-    constexpr int COUT = 4 * CMID;
+    constexpr int COUT = COUT_ > 0 ? COUT_ : 4 * CMID;
+    static_assert(HAS_RES || (!HAS3X3 && NRED == 0), "only conv_c alone runs without a residual");
     constexpr int BM = RP * NW, NT = NW * 64;      // every wave owns RP pixel rows in P2 (16 only without conv_b)
     static_assert(RP == 32 || (RP == 16 && !HAS3X3), "rows per wave");
     constexpr int ROWB = CMID * 2;               // bytes per pixel of t1 / T2
@@ -1339,15 +1343,25 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         // ---- conv_c alone: every wave reads the fragments of ITS rows straight from global memory (each byte of the
         //      tile is needed by one wave only, so an LDS round trip and its two barriers would buy nothing) ----------
         FAV_T_STAGE_WC(0);
+        // row b*16 + frow of this wave: output pixel m -> its input pixel (the same one unless the 1x1 is strided);
+        // offsets are relative to the first frame the tile touches, rows beyond M fail the range check (zeros)
+        const int v0 = (int)fastdiv((uint32_t)m0, p.div_hw);
         const __amdgpu_buffer_rsrc_t srd_a =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + (long long)m0 * CMID), 0, rows_valid * ROWB, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + (long long)v0 * p.in_HW * CMID), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
-        for (int b = 0; b < TM2; ++b)
+        for (int b = 0; b < TM2; ++b) {
+            const int m = m0 + wave * RP + b * 16 + frow;
+            const uint32_t vl = fastdiv((uint32_t)m, p.div_hw);
+            const uint32_t pix = (uint32_t)m - vl * (uint32_t)p.HW;
+            const uint32_t oy = fastdiv(pix, p.div_w), ox = pix - oy * (uint32_t)p.W;
+            const uint32_t roff = m < p.M ? (((vl - (uint32_t)v0) * (uint32_t)p.in_HW + oy * (uint32_t)(p.in_stride * p.in_W) + ox * (uint32_t)p.in_stride) * ROWB)
+                                          : 0x80000000u;
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
-                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(srd_a, (wave * RP + b * 16 + frow) * ROWB + (ks * 4 + fq) * 16, 0, 0);
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(srd_a, (int)(roff + (ks * 4 + fq) * 16), 0, 0);
                 t2f[b][ks] = make_uint4(v[0], v[1], v[2], v[3]);
             }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights (and the fragments)
         __syncthreads();
     }
@@ -1361,7 +1375,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
     u32x4_t rnext[TM2][2], rcur[TM2][2];
 #define FAV_T_LOAD_RES(J)                                                                                        \
-    _Pragma("unroll") for (int b = 0; b < TM2; ++b) {                                                            \
+    if (HAS_RES) _Pragma("unroll") for (int b = 0; b < TM2; ++b) {                                               \
         const int off = ((wave * RP + b * 16 + frow) * COUT + (J) * 64 + fq * 16) * 2;                           \
         rnext[b][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off, 0, 0);                                 \
         rnext[b][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off + 16, 0, 0);                            \
@@ -1391,11 +1405,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         const unsigned char* const wab = regb + WCN * WC_BYTES + ((j + 1) & 1) * WA_BYTES;
         // residual of THIS chunk has landed; then the requests of the NEXT chunk (the other weight buffers: every
         // wave is past chunk j-1, the barrier at its end says so)
+        if (HAS_RES) {
 #pragma unroll
-        for (int b = 0; b < TM2; ++b) {
-            asm volatile("" : "+v"(rnext[b][0]), "+v"(rnext[b][1]));
-            rcur[b][0] = rnext[b][0];
-            rcur[b][1] = rnext[b][1];
+            for (int b = 0; b < TM2; ++b) {
+                asm volatile("" : "+v"(rnext[b][0]), "+v"(rnext[b][1]));
+                rcur[b][0] = rnext[b][0];
+                rcur[b][1] = rnext[b][1];
+            }
         }
         if (j + 1 < NCHUNK) {
             if (WC2) FAV_T_STAGE_WC(j + 1);
@@ -1455,14 +1471,18 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                     float v[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc2[2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]);
-                    const uint32_t rw[4] = {rcur[b][g][0], rcur[b][g][1], rcur[b][g][2], rcur[b][g][3]};
+                    if (HAS_RES) {
+                        const uint32_t rw[4] = {rcur[b][g][0], rcur[b][g][1], rcur[b][g][2], rcur[b][g][3]};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[2 * k] = __fadd_rn(v[2 * k], bf16_bits_to_f32(rw[k] & 0xFFFFu));
-                        v[2 * k + 1] = __fadd_rn(v[2 * k + 1], bf16_bits_to_f32(rw[k] >> 16));
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] = __fadd_rn(v[2 * k], bf16_bits_to_f32(rw[k] & 0xFFFFu));
+                            v[2 * k + 1] = __fadd_rn(v[2 * k + 1], bf16_bits_to_f32(rw[k] >> 16));
+                        }
                     }
+                    if (RELU) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
                     if (p.drop.site >= 0) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = FAV_DROP_APPLY(v[k], draws, 8 * g + k, p.drop);
@@ -1505,7 +1525,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         if (j + 1 < NCHUNK) {
             // WC2: the youngest operations are the next residual loads and this chunk's stores; otherwise the Wc pieces
             // were issued after the residual loads, so only the stores may stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC2 ? 4 * TM2 : 2 * TM2) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WC2 && HAS_RES) ? 4 * TM2 : 2 * TM2) : "memory");
             if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 10] = __builtin_amdgcn_s_memtime();
             FAV_BAR();
             if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 11] = __builtin_amdgcn_s_memtime();

@@ -104,3 +104,17 @@ def test_tail_rejects_unsupported_shapes(lib):
     d = _lib.FavTailDesc(x.data_ptr(), None, None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, None, None,
                          1, 8, 8, 96, 0, drop_desc())
     assert lib.fav_op_bottleneck_tail(C.byref(d), None) == 1      # FAV_ERR_INVALID_ARG, nothing launched
+
+
+@pytest.mark.parametrize("stride,H,W,n", [(2, 56, 56, 6), (2, 30, 26, 41), (1, 28, 28, 7)])
+def test_projection_shortcut_on_the_row_owning_kernel(lib, stride, H, W, n):
+    """1x1 / stride s, 256 -> 512, no residual, no ReLU (a stage's projection shortcut) takes the tail kernel's
+    row-owning path when the launch is large enough: bit-identical to the MFMA-model oracle, ragged last tile included."""
+    rng = np.random.default_rng(stride * 100 + H + n)
+    x = O.bf16_round((rng.standard_normal((n, H, W, 256)) * np.exp2(rng.integers(-2, 3, (n, H, W, 256)))).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((512, 1, 1, 256)) * np.sqrt(1.0 / 256)).astype(np.float32))
+    b = (rng.standard_normal(512) * 0.2).astype(np.float32)
+    got = run_conv(lib, x, w, b, None, stride, 0, relu=0)
+    ref = O.epilogue(O.conv_acc_exact(x, w, 1, 1, stride, 0, mode="mfma"), b, relu=False)
+    assert got.shape == ref.shape and got.shape[0] * got.shape[1] * got.shape[2] >= 4096
+    assert np.array_equal(got, ref), f"{np.mean(got != ref):.5f} of elements differ"
