@@ -122,6 +122,13 @@ struct fav_handle {
     std::vector<hipEvent_t> ev_chunk;
     void* a1 = nullptr;
     size_t a1_bytes = 0;
+    // deep ensemble (BASELINE configs[3]): the members are independent networks over the same frames, so each runs on
+    // its own stream with its own rotating buffers (member 0: the handle's) and the head waits for all of them - at
+    // the per-GPU share of 32 frames a single member leaves most CUs idle in layers 3-4.  FAV_ENS_STREAMS=0: serial.
+    struct MemberWs { void* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; void* a1 = nullptr; std::vector<void*> phase_out;
+                      hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    std::vector<MemberWs> mws;
+    hipEvent_t ev_members = nullptr;
     std::vector<void*> phase_out;   // output tensor of each phase
     float* logits = nullptr;        // [T][max_batch][cpad]
     int cpad = 0;
@@ -1016,20 +1023,46 @@ fav_status plan_memory(fav_handle* h) {
     }
     HIP_TRY(h, hipMalloc((void**)&h->logits, (size_t)nv_max * h->n_members * h->cpad * 4 + 256));
     h->phase_out.back() = h->logits;
+    static const int ens_streams = [] { const char* e = getenv("FAV_ENS_STREAMS"); return e ? atoi(e) : 1; }();
+    if (h->n_members > 1 && ens_streams && h->pipe_first < 0) {
+        h->mws.resize(h->n_members);
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_members, hipEventDisableTiming));
+        for (int m = 0; m < h->n_members; ++m) {
+            fav_handle::MemberWs& w = h->mws[m];
+            HIP_TRY(h, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+            w.phase_out.assign(h->phases.size(), nullptr);
+            if (m == 0) {
+                for (int i = 0; i < 5; ++i) w.act[i] = h->act[i];
+                w.a1 = h->a1;
+                for (size_t i = 0; i + 1 < h->phases.size(); ++i) w.phase_out[i] = h->phase_out[i];
+                continue;
+            }
+            for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&w.act[i], act_bytes));
+            HIP_TRY(h, hipMalloc(&w.a1, a1_bytes));
+            for (size_t i = 0; i + 1 < h->phases.size(); ++i) {
+                const Phase& p = h->phases[i];
+                const long long dom = p.suffix ? nv_max : c.max_batch;
+                HIP_TRY(h, hipMalloc(&w.phase_out[i], (size_t)dom * p.out_elems * p.out_bytes_per_elem + 256));
+            }
+        }
+    }
     return FAV_OK;
 }
 
 // ------------------------------------------------------------------ execution
 fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, int n, long long first_index,
-                      hipStream_t s, long long v_begin, long long v_end, void** act_set) {
+                      hipStream_t s, long long v_begin, long long v_end, void** act_set, const fav_handle::MemberWs* ws = nullptr) {
     const fav_config& c = h->cfg;
     const Phase& p = h->phases[pi];
     const long long dom = p.suffix ? (long long)n * h->T_eff : n;
-    const char* pin_base = pi == 0 ? (const char*)images : (const char*)h->phase_out[pi - 1];
+    const std::vector<void*>& phase_out = ws ? ws->phase_out : h->phase_out;
+    void* const a1 = ws ? ws->a1 : h->a1;
+    const char* pin_base = pi == 0 ? (const char*)images : (const char*)phase_out[pi - 1];
     const int in_bpe = pi == 0 ? (layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4) : h->phases[pi - 1].out_bytes_per_elem;
     // a suffix phase that follows the prefix reads frame (v % n); later phases read virtual frame v
     const bool in_is_virtual = pi > 0 && h->phases[pi - 1].suffix;
-    char* pout_base = (char*)h->phase_out[pi];
+    char* pout_base = (char*)phase_out[pi];
     const uint32_t thr = (uint32_t)std::lround((double)c.dropout_p * 256.0);
     const float scale = thr > 0 ? (float)(1.0 / (1.0 - thr / 256.0)) : 1.0f;
     float istd[3] = {1.0f / c.stdev[0], 1.0f / c.stdev[1], 1.0f / c.stdev[2]};
@@ -1044,7 +1077,7 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                     if (!in_is_virtual && p.suffix) return (void*)pin_base;  // entry dropout indexes v % n itself
                     return (void*)(pin_base + (size_t)v0 * p.in_elems * in_bpe);
                 case B_PHASE_OUT: return (void*)(pout_base + (size_t)v0 * p.out_elems * p.out_bytes_per_elem);
-                case B_A1: return h->a1;
+                case B_A1: return a1;
                 case B_NONE: return nullptr;
                 default: return act_set[id];
             }
@@ -1124,6 +1157,17 @@ void free_all(fav_handle* h) {
     if (h->ev_join_b) (void)hipEventDestroy(h->ev_join_b);
     for (auto e : h->ev_chunk) (void)hipEventDestroy(e);
     if (h->a1) (void)hipFree(h->a1);
+    for (size_t m = 0; m < h->mws.size(); ++m) {
+        fav_handle::MemberWs& w = h->mws[m];
+        if (m > 0) {
+            for (int i = 0; i < 5; ++i) if (w.act[i]) (void)hipFree(w.act[i]);
+            if (w.a1) (void)hipFree(w.a1);
+            for (size_t i = 0; i + 1 < w.phase_out.size(); ++i) if (w.phase_out[i]) (void)hipFree(w.phase_out[i]);
+        }
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+        if (w.done) (void)hipEventDestroy(w.done);
+    }
+    if (h->ev_members) (void)hipEventDestroy(h->ev_members);
     for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
     if (h->logits) (void)hipFree(h->logits);
     if (h->host_stage) (void)hipFree(h->host_stage);
@@ -1417,6 +1461,22 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
         for (auto& L : h->layers) { L.w = L.w_m[0]; L.b = L.b_m[0]; }
         fav_status st = run_vit(h, images, layout, n, s);
         if (st != FAV_OK) return st;
+    } else if (!h->mws.empty()) {
+        // members side by side: fork from the caller's stream, one stream per member, join before the head
+        HIP_TRY(h, hipEventRecord(h->ev_members, s));
+        for (int member = 0; member < h->n_members; ++member) {
+            fav_handle::MemberWs& w = h->mws[member];
+            for (auto& L : h->layers) { L.w = L.w_m[member]; L.b = L.b_m[member]; }   // read when the launches are enqueued
+            w.phase_out.back() = (char*)h->logits + (size_t)member * n * h->cpad * 4;
+            HIP_TRY(h, hipStreamWaitEvent(w.stream, h->ev_members, 0));
+            for (size_t pi = 0; pi < h->phases.size(); ++pi) {
+                const long long dom = h->phases[pi].suffix ? (long long)n * h->T_eff : n;
+                fav_status st = run_chunks(h, pi, images, layout, n, first_index, w.stream, 0, dom, w.act, &w);
+                if (st != FAV_OK) return st;
+            }
+            HIP_TRY(h, hipEventRecord(w.done, w.stream));
+        }
+        for (int member = 0; member < h->n_members; ++member) HIP_TRY(h, hipStreamWaitEvent(s, h->mws[member].done, 0));
     } else
     for (int member = 0; member < h->n_members; ++member) {
     for (auto& L : h->layers) { L.w = L.w_m[member]; L.b = L.b_m[member]; }
