@@ -75,6 +75,7 @@ _SIGNATURES = {
     "fav_load_member_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "fav_destroy": (None, [C.c_void_p]),
     "fav_check_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "fav_plan_schedule": (C.c_int, [C.POINTER(FavConfig), C.c_int32, C.c_char_p, C.c_size_t]),
     "fav_last_error": (C.c_char_p, [C.c_void_p]),
     "fav_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fav_classify_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,

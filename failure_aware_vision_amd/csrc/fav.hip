@@ -129,6 +129,7 @@ struct fav_handle {
                       hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     std::vector<MemberWs> mws;
     hipEvent_t ev_members = nullptr;
+    bool plan_no_fuse = false;      // fav_plan_schedule: build the layer-by-layer schedule (the fused one's reference)
     std::vector<void*> phase_out;   // output tensor of each phase
     float* logits = nullptr;        // [T][max_batch][cpad]
     int cpad = 0;
@@ -798,7 +799,7 @@ fav_status build_graph(fav_handle* h) {
                 TailGeom tg;
                 const bool tail_3x3 = (s == 1) && pl <= 128;
                 if (pl > 128 && (nred != pl || !tail_wide_reduce())) nred = 0;   // wide blocks: the expanding 1x1 (+ the next reduce inside a stage)
-                bool fuse = tail_enabled() && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()));
+                bool fuse = tail_enabled() && !h->plan_no_fuse && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()));
                 if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {
                     nred = 0;
                     fuse = tail_geometry(pl, 0, tail_3x3, Wn, &tg);
@@ -1331,6 +1332,32 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out) {
     if (st == FAV_OK && !h->vit) st = plan_memory(h);
     if (st != FAV_OK) { g_create_error = h->err; free_all(h); delete h; return st; }
     *out = h;
+    return FAV_OK;
+}
+
+// The static schedule of a configuration as text, one line per op - no device needed (tests/test_host.py replays it
+// symbolically and checks that the fused schedule computes the same dataflow as the layer-by-layer one).
+//   "op <i> kind=<k> phase=<p> layer=<l> lc=<l> la=<l> in=<b> res=<b> out=<b> out2=<b> site=<s> relu=<r>"
+// buffers: 0..4 rotating, 5 im2col matrix, -1 frames, -2 phase input, -3 phase output, -4 none.
+fav_status fav_plan_schedule(const fav_config* cfg, int32_t flags, char* out, size_t cap) {
+    if (!cfg || !out || cap < 2 || cfg->struct_size != sizeof(fav_config) || cfg->arch < 0 || cfg->arch > 1) return FAV_ERR_INVALID_ARG;
+    fav_handle h;
+    h.cfg = *cfg;
+    h.n_members = cfg->n_members > 1 ? cfg->n_members : 1;
+    h.plan_no_fuse = (flags & 1) != 0;
+    fav_status st = build_graph(&h);
+    if (st != FAV_OK) { snprintf(out, cap, "%s", h.err.c_str()); return st; }
+    std::string txt;
+    for (size_t i = 0; i < h.ops.size(); ++i) {
+        const Op& o = h.ops[i];
+        int phase = -1;
+        for (size_t pi = 0; pi < h.phases.size(); ++pi)
+            if ((int)i >= h.phases[pi].op_begin && (int)i < h.phases[pi].op_end) phase = (int)pi;
+        txt += fmt("op %zu kind=%d phase=%d layer=%d lc=%d la=%d in=%d res=%d out=%d out2=%d site=%d relu=%d suffix=%d\n", i, (int)o.kind, phase, o.layer,
+                   o.layer_c, o.layer_a, o.in, o.res, o.out, o.out2, o.site, o.relu, phase >= 0 ? (int)h.phases[phase].suffix : 0);
+    }
+    if (txt.size() + 1 > cap) return FAV_ERR_INVALID_ARG;
+    memcpy(out, txt.c_str(), txt.size() + 1);
     return FAV_OK;
 }
 

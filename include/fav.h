@@ -97,6 +97,9 @@ void fav_destroy(fav_handle* h);
  * alignment), without a device or a handle; fav_load_*_weights runs it first.  err (may be NULL)
  * receives a message.  The blob is file-supplied, hence untrusted. */
 fav_status fav_check_blob(const void* blob_host, size_t size, char* err, size_t err_cap);
+/* The static launch schedule of a configuration (ResNet archs) as text, one line per op; needs no device.
+ * flags bit 0: the layer-by-layer schedule (no fused bottleneck tails).  A test / inspection hook. */
+fav_status fav_plan_schedule(const fav_config* cfg, int32_t flags, char* out, size_t cap);
 const char* fav_last_error(const fav_handle* h); /* h may be NULL: error of the last failed fav_create */
 int32_t fav_abi_version(void);
 

@@ -284,3 +284,106 @@ def test_sharded_classify_nccl_world2(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+# ---- the static launch schedule, replayed symbolically (no GPU) ---------------------------------------------------
+def _plan(lib, arch, flags=0, **kw):
+    from failure_aware_vision_amd import _lib
+    cfg = _lib.FavConfig()
+    lib.fav_default_config(C.byref(cfg), arch)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    buf = C.create_string_buffer(1 << 17)
+    st = lib.fav_plan_schedule(C.byref(cfg), flags, buf, len(buf))
+    assert st == 0, buf.value
+    ops = []
+    for line in buf.value.decode().splitlines():
+        f = dict(kv.split("=") for kv in line.split()[2:])
+        ops.append({k: int(v) for k, v in f.items()})
+    return ops
+
+
+def _replay(ops):
+    """Every buffer holds a symbolic tensor (a nested tuple naming the ops that made it).  Rotating buffers do not
+    survive a phase boundary (only the phase output does), a read of a buffer nothing wrote is an error, and an op may
+    not write a buffer it reads.  Returns the symbol of the last phase's output (the logits)."""
+    bufs, phase, phase_in, phase_out = {}, 0, None, None
+    NONE, FRAMES, PIN, POUT = -4, -1, -2, -3
+
+    def rd(b):
+        if b == NONE:
+            return None
+        if b == FRAMES:
+            return "frames"
+        if b == PIN:
+            assert phase_in is not None
+            return phase_in
+        return bufs[b]          # KeyError = read of a buffer nothing wrote in this phase
+
+    def wr(b, sym):
+        nonlocal phase_out
+        if b == POUT:
+            phase_out = sym
+        elif b != NONE:
+            bufs[b] = sym
+
+    for o in ops:
+        if o["phase"] != phase:
+            assert phase_out is not None, "phase ended without an output"
+            phase, phase_in, phase_out, bufs = o["phase"], phase_out, None, {}
+        x, r = rd(o["in"]), rd(o["res"])
+        writes = [b for b in (o["out"], o["out2"]) if b >= 0]
+        assert len(set(writes)) == len(writes) and not (set(writes) & {o["in"], o["res"]}), o
+        k = o["kind"]
+        if k == 0:
+            wr(o["out"], ("im2col", x))
+        elif k == 1:
+            wr(o["out"], ("conv", o["layer"], x, r, o["relu"], o["site"]))
+        elif k == 2:
+            wr(o["out"], ("maxpool", x))
+        elif k == 3:
+            wr(o["out"], ("avgpool", x, o["site"]))
+        elif k == 4:
+            wr(o["out"], ("entry_dropout", o["site"], x))
+        elif k == 5:
+            t2 = ("conv", o["layer"], x, None, 1, -1) if o["layer"] >= 0 else x
+            y = ("conv", o["lc"], t2, r, 1, o["site"])
+            wr(o["out"], y)
+            if o["la"] >= 0:
+                wr(o["out2"], ("conv", o["la"], y, None, 1, -1))
+            else:
+                assert o["out2"] == NONE
+        else:
+            raise AssertionError(o)
+    return phase_out
+
+
+def test_fused_schedule_computes_the_layer_by_layer_dataflow(lib):
+    """fav_plan_schedule (no device): for every architecture, dropout policy, regrouping point and frame size the schedule
+    with fused bottleneck tails must be the same computation as the layer-by-layer one - same convolutions, same inputs,
+    same residuals, same dropout sites - and may never read a rotating buffer across a phase boundary."""
+    from failure_aware_vision_amd import weights
+    n_tail = 0
+    for arch in (1, 0):
+        nb = weights.n_blocks(arch)
+        masks = [0, weights.site_mask_for(arch, "all_blocks"), weights.site_mask_for(arch, "last_layer"),
+                 weights.site_mask_for(arch, "layer4+fc"), 0b101000, 1 << 3, (1 << nb) | 1]
+        for mask in masks:
+            for regroup in (-1, 0, 1, 3, 7, 8, nb):
+                for hw in ((224, 224), (64, 64), (240, 320), (1024, 2048)):
+                    kw = dict(in_h=hw[0], in_w=hw[1], site_mask=mask, n_samples=3 if mask else 1, dropout_p=0.1 if mask else 0.0,
+                              regroup_block=regroup)
+                    fused, plain = _plan(lib, arch, 0, **kw), _plan(lib, arch, 1, **kw)
+                    assert not any(o["kind"] == 5 for o in plain)
+                    n_tail += sum(o["kind"] == 5 for o in fused)
+                    a, b = _replay(fused), _replay(plain)
+                    assert a == b, (arch, mask, regroup, hw)
+                    assert a[0] == "conv" and "avgpool" in (a[2][0], a[2][2][0] if a[2][0] == "entry_dropout" else "")   # fc over the pooled features
+    assert n_tail > 1000                                                  # the sweep really exercised fused schedules
+    # the headline configuration: which ops it consists of
+    ops = _plan(lib, 1, 0, site_mask=weights.site_mask_for(1, "all_blocks"), n_samples=30, dropout_p=0.1)
+    tails = [o for o in ops if o["kind"] == 5]
+    assert len(tails) == 13 and sum(o["la"] >= 0 for o in tails) == 5 and sum(o["layer"] >= 0 for o in tails) == 6
+    assert sum(o["kind"] == 4 for o in ops) == 1 and len({o["phase"] for o in ops}) == 3
+    # the validation mode keeps the separate launches
+    assert not any(o["kind"] == 5 for o in _plan(lib, 1, 0, math_mode=1))
