@@ -144,8 +144,9 @@ def test_mc_dropout_t30_fixture(r50_blob):
     bad = l2 != d["labels"]
     note(f"T=30 x 64 frames, production vs exact-mode fixture: {bad.sum()} labels differ, largest gap among them "
          f"{d['gap'][bad].max() if bad.any() else 0:.4f}, max |dconf| {np.abs(c2 - d['conf']).max():.4f}")
-    assert bad.mean() <= 0.10 and np.all(d["gap"][bad] < 0.05), (bad.mean(), d["gap"][bad])
-    assert np.abs(c2 - d["conf"]).max() < 0.05
+    # measured: no label differs, max |dconf| 0.005 (averaging 30 samples hides the instruction's truncations)
+    assert bad.mean() <= 0.05 and np.all(d["gap"][bad] < 0.03), (bad.mean(), d["gap"][bad])
+    assert np.abs(c2 - d["conf"]).max() < 0.02
     be.close()
 
 
