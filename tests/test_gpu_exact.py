@@ -168,3 +168,32 @@ def test_resnet50_production_mode_bitwise(r50_blob):
     small = synth.synthetic_frames_u8(3, 64, 64, seed=9)
     _exact_case("resnet50", r50_blob[0], small, first_index=5, hw=(64, 64), math="bf16", n_samples=2,
                 dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+
+
+def test_conv3x3_too_wide_for_the_staged_patch_falls_back_to_the_generic_kernel(lib):
+    """A frame so wide that the staged-patch 3x3 kernel's LDS image (256 + 2W + 2 pixels) exceeds 160 KB: launch_conv
+    must take the generic implicit-GEMM kernel and still match the oracle bit for bit (VERDICT r1, weak #12)."""
+    rng = np.random.default_rng(77)
+    n, H, W, c = 2, 4, 700, 64          # patch would be (256 + 1402) * 128 B = 212 KB; M = 5600 >= the 2048-row threshold
+    x = O.bf16_round((rng.standard_normal((n, H, W, c)) * np.exp2(rng.integers(-2, 3, (n, H, W, c)))).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((c, 3, 3, c)) * np.sqrt(2.0 / (9 * c))).astype(np.float32))
+    b = (rng.standard_normal(c) * 0.2).astype(np.float32)
+    got = run_conv(lib, x, w, b, None, 1, 1, relu=1, math_mode=0)
+    ref = O.epilogue(O.conv_acc_exact(x, w, 3, 3, 1, 1, mode="mfma"), b, relu=True)
+    assert np.array_equal(got, ref), f"{np.mean(got != ref):.5f} of elements differ"
+
+
+def test_resnet50_wide_frames_mix_fused_tails_and_fallbacks(r50_blob):
+    """64 x 1408 frames: layer 1's fused tails still fit their LDS image (W = 352), layer 2's (W = 176, 256-pixel tiles)
+    do not and fall back to the separate launches - the schedule mixes both and the logits stay bit-identical to the
+    MFMA-model oracle."""
+    blob, _ = r50_blob
+    model = O.parse_blob(blob)
+    frames = synth.synthetic_frames_u8(2, 64, 1408, seed=13)
+    be = Backend("resnet50", blob, in_hw=(64, 1408), max_batch=2, n_samples=2, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    be.classify(torch.from_numpy(frames).cuda(), first_index=5)
+    got = be.logits().cpu().numpy()
+    be.close()
+    cfg = O.ClassifyConfig(n_samples=2, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact="mfma")
+    ref = O.classify(model, frames, cfg, img_ids=np.arange(5, 7), return_logits=True)[2]
+    assert np.array_equal(got, ref)
