@@ -455,8 +455,14 @@ inline int tail_nw(int cmid) { return cmid == 128 ? 8 : 4; }
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     // 256 mid channels (layer 3): the expanding 1x1 alone, or with the next block's reduce (then 8 waves x 16 rows)
-    if (cmid == 256) { if (has3x3 || !(nred == 0 || nred == 256)) return false; }
+    if (cmid == 256) { if ((has3x3 && nred != 0) || !(nred == 0 || nred == 256)) return false; }
     else if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
+    if (cmid == 256 && has3x3) {
+        // conv_b as the generic 256 x 256 x 64 loop (two 64 KB stages); T2, then the Wc buffers, reuse those 128 KB
+        g->patch_bytes = 0; g->rega_bytes = 128 * 1024; g->nw = 8; g->rp = 32; g->wc2 = 1;
+        g->lds_bytes = g->rega_bytes + (cmid + 4 * cmid) * 5 + 16;
+        return true;
+    }
     const int rp = (cmid == 256 && nred == 256) ? 16 : 32;
     const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2, nw = (cmid == 256 && nred == 256) ? 8 : tail_nw(cmid), bm = rp * nw;
     const int patch = has3x3 ? (int)((((long long)(bm + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
@@ -488,6 +494,12 @@ bool tail_wide() {
 // measured 3.01 ms against 1.77 ms (expand alone as a tail) + 0.95 ms (generic reduce) -> off by default
 bool tail_wide_reduce() {
     static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE_REDUCE"); return e ? atoi(e) : 0; }();
+    return on != 0;
+}
+
+// 256 mid channels: conv_b (generic loop) + conv_c in one launch.  FAV_TAIL_WIDE3X3=0 keeps the 3x3 as its own launch.
+bool tail_wide3x3() {
+    static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE3X3"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
 
@@ -568,6 +580,8 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     } else if (cmid == 128) {
         if (has3x3) { if (nred == 0) FAV_TAIL_W(128, 0, true, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, true, 2, 8); }
         else { if (nred == 0) FAV_TAIL_W(128, 0, false, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, false, 2, 8); }
+    } else if (nred == 0 && has3x3) {
+        FAV_TAIL(256, 0, true, 2, 8, true);
     } else if (nred == 0) {
         FAV_TAIL_W(256, 0, false, 2, 4);
     } else {
@@ -797,7 +811,7 @@ fav_status build_graph(fav_handle* h) {
                 const int next_pl = (bi + 1 < A.depths[st]) ? pl : (st < 3 ? A.planes[st + 1] : 0);
                 int nred = boundary_after ? 0 : next_pl;
                 TailGeom tg;
-                const bool tail_3x3 = (s == 1) && pl <= 128;
+                const bool tail_3x3 = (s == 1) && (pl <= 128 || (pl == 256 && tail_wide3x3()));
                 if (pl > 128 && (nred != pl || !tail_wide_reduce())) nred = 0;   // wide blocks: the expanding 1x1 (+ the next reduce inside a stage)
                 bool fuse = tail_enabled() && !h->plan_no_fuse && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()));
                 if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {

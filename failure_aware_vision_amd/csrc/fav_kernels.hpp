@@ -1136,7 +1136,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     constexpr int G3 = NRED / 64;                // 64-channel groups of conv_a's output
     constexpr int WC_BYTES = 64 * ROWB;          // Wc chunk: 64 rows x CMID k, as CB sub tiles of 64 x 64
     constexpr int WA_BYTES = NRED * 128;         // Wa chunk: NRED rows x 64 k
-    constexpr int WCN = WC2 ? 2 : 1;             // Wc buffers: 2 = requested a chunk ahead; 1 = requested behind a barrier after step A
+    // Wc buffers: 2 = requested a chunk ahead; 1 = requested behind a barrier after step A; 4 (generic conv_b, whose 128 KB
+    // of stages are free in P2) = requested two chunks at a time, ONE workgroup barrier per two chunks (BARQ)
+    constexpr int WCN = (HAS3X3 && CMID == 256) ? 4 : (WC2 ? 2 : 1);
+    constexpr int BARQ = WCN == 4 ? 2 : 1;
     constexpr int P2W = WCN * WC_BYTES + 2 * WA_BYTES;
     constexpr int RING = HAS3X3 ? NS * SLOT : 0;
     constexpr int REGB = RING > P2W ? RING : P2W;
@@ -1145,11 +1148,16 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     static_assert(BR >= 1 && TN1 >= 1 && TM2 >= 1 && WC_PIECES % NW == 0 && (NRED == 0 || WA_PIECES % NW == 0), "tile shape");
     static_assert(!HAS3X3 || (NKT % NS == 0 && WC_BYTES <= SLOT), "Wc buffer 0 = ring slot 0, free during the last NS - 1 steps");
     constexpr bool WA0_EARLY = !HAS3X3 || WCN * WC_BYTES + WA_BYTES >= RING;   // chunk 0's Wa buffer lies beyond the P1 ring
+    // 256 mid channels: the patch of a 256-pixel tile would not fit, so conv_b runs as the generic 256 x 256 x 64 loop
+    // (BOTH operands DMA'd per K tile, two stages = 128 KB); T2 then takes that same 128 KB, and once its fragments
+    // sit in registers the Wc buffers of P2 reuse it from offset 0 (no region B, no Y chunk: NRED = 0)
+    constexpr bool P1G = HAS3X3 && CMID == 256;
+    static_assert(!P1G || (NW == 8 && NS == 2 && RP == 32 && NRED == 0 && WC2), "generic conv_b: 8 waves, two stages, conv_c alone behind it");
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
     // [region A | region B: weight ring (P1) / Wc x2, Wa x2 (P2) | biases (16-channel chunks 20 floats apart) | 16 zero bytes]
     unsigned char* const ych = tsm;                                // P2: Y chunk [BM][64] bf16, chunk ^= row & 7
-    unsigned char* const regb = tsm + p.rega_bytes;
-    const int bias_off = p.rega_bytes + REGB;
+    unsigned char* const regb = P1G ? tsm : tsm + p.rega_bytes;
+    const int bias_off = p.rega_bytes + (P1G ? 0 : REGB);
     float* const bias_b_s = (float*)(tsm + bias_off);
     float* const bias_c_s = bias_b_s + (CMID / 16) * 20;
     float* const bias_a_s = bias_c_s + (COUT / 16) * 20;
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     if (tid < 4) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)tsm);
-    const uint32_t lds_regb = lds_base + (uint32_t)p.rega_bytes;
+    const uint32_t lds_regb = lds_base + (P1G ? 0u : (uint32_t)p.rega_bytes);
     constexpr uint32_t OOB = 0x80000000u;
     // weights: rows of 128 B (64 k), a piece = 8 rows; lane -> row l>>3, physical slot l&7 holds chunk (l&7)^(row&7)
     const int wrow = lane >> 3, wch = (lane & 7) ^ (wrow & 7);
@@ -1206,6 +1214,95 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     if (NRED > 0 && WA0_EARLY) FAV_T_STAGE_WA(0);   // oldest request of the block (its buffer is not part of the P1 ring)
     if (HAS3X3) {
         f32x4_t acc[TN1][TM];
+#pragma unroll
+        for (int a = 0; a < TN1; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (P1G) {
+            // ---- P1 (generic): K tile kt = tap kt / CB, channels 64 * (kt % CB); A tile [BM][64 k] gathered per tap
+            //      (pixel m + (r-1) W + (s-1) of the flattened tensor, or zeros where the tap leaves the frame), B tile
+            //      [CMID][64 k]; the same k order and the same loop as conv_igemm_kernel<256, 256, 64, 2> ----------------
+            constexpr int STG = 2 * 32768, AR = 32768 / 1024 / NW;
+            static_assert(BM == 256 && AR == 4 && BR == 4, "generic conv_b tile");
+            const __amdgpu_buffer_rsrc_t srd_a =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + ((long long)m0 - W - 1) * CMID), 0, 0x7FFFFFFF, 0x00020000);
+            const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, CMID * 9 * CMID * 2, 0x00020000);
+            uint32_t a_voff[AR], a_mask[AR], b_voff[BR];
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int row = (wave * AR + i) * 8 + wrow, m = m0 + row;
+                uint32_t mk = 0;
+                if (m < p.M) {
+                    const uint32_t vl = fastdiv((uint32_t)m, p.div_hw);
+                    const uint32_t pix = (uint32_t)m - vl * (uint32_t)p.HW;
+                    const uint32_t y = fastdiv(pix, p.div_w), x = pix - y * (uint32_t)W;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int s2 = 0; s2 < 3; ++s2)
+                            if ((unsigned)((int)y + r - 1) < (unsigned)p.H && (unsigned)((int)x + s2 - 1) < (unsigned)W) mk |= 1u << (r * 3 + s2);
+                }
+                a_mask[i] = mk;
+                a_voff[i] = (uint32_t)(row * ROWB + wch * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) b_voff[i] = (uint32_t)((((wave * BR + i) * 8 + wrow) * (9 * CMID) + wch * 8) * 2);
+            const uint32_t lds_a = lds_base + wave_u * (AR * 1024), lds_b = lds_base + 32768 + wave_u * (BR * 1024);
+            int s_tap = 0, s_cb = 0, s_r = 0, s_s = 0;     // position of the NEXT K tile to stage
+#define FAV_T_GSTAGE(BUF, KT)                                                                                    \
+    do {                                                                                                         \
+        const uint32_t soff_a = (uint32_t)((s_r * W + s_s) * ROWB + s_cb * 128);                                 \
+        _Pragma("unroll") for (int i = 0; i < AR; ++i)                                                           \
+            lds_dma16(srd_a, ((a_mask[i] >> s_tap) & 1u) ? a_voff[i] : OOB, soff_a,                              \
+                      __builtin_amdgcn_readfirstlane(lds_a + (BUF) * STG + i * 1024));                           \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                           \
+            lds_dma16(srd_b, b_voff[i], (uint32_t)((KT) * 128),                                                  \
+                      __builtin_amdgcn_readfirstlane(lds_b + (BUF) * STG + i * 1024));                           \
+        if (++s_cb == CB) {                                                                                      \
+            s_cb = 0; ++s_tap;                                                                                   \
+            if (++s_s == 3) { s_s = 0; ++s_r; }                                                                  \
+        }                                                                                                        \
+    } while (0)
+            FAV_T_GSTAGE(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
+            int cur = 0;
+            for (int kt = 0; kt < NKT; ++kt) {
+                const unsigned char* As = tsm + cur * STG;
+                const unsigned char* Bs = As + 32768;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    // the next tile's DMA goes out after the first MFMA group: its address arithmetic runs under matrix work
+                    if (kk == 1 && kt + 1 < NKT) FAV_T_GSTAGE(cur ^ 1, kt + 1);
+                    uint4 fx[TM], fw[TN1];
+                    const int ch = kk * 4 + fq;
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const int row = wm * 64 + b * 16 + frow;
+                        fx[b] = *(const uint4*)(As + row * 128 + ((ch ^ (row & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int a = 0; a < TN1; ++a) {
+                        const int row = wn * (CMID / WN1) + a * 16 + frow;
+                        fw[a] = *(const uint4*)(Bs + row * 128 + ((ch ^ (row & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int a = 0; a < TN1; ++a)
+#pragma unroll
+                        for (int b = 0; b < TM; ++b) {
+                            union { uint4 u; bf16x8_t v; } ua, ub;
+                            ua.u = fw[a];
+                            ub.u = fx[b];
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[a][b], 0, 0, 0);
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+#undef FAV_T_GSTAGE
+        } else {
         // ---- patch: flattened input pixels [m0 - W - 1, m0 + BM + W + 1), all CMID channels --------------------
         const long long g0 = (long long)m0 - W - 1;
         const long long gbase = g0 > 0 ? g0 : 0;
@@ -1252,10 +1349,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             }
             tapmask[b] = mk;
         }
-#pragma unroll
-        for (int a = 0; a < TN1; ++a)
-#pragma unroll
-            for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
         __syncthreads();
         if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
@@ -1310,6 +1403,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
 #undef FAV_T_HSTAGE
+        }
         if (NRED > 0 && !WA0_EARLY) FAV_T_STAGE_WA(0);
         if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 2] = wall_clock64();
         // ---- P1e: T2 = bf16(relu(acc + bias_b)) -> LDS [BM][CMID], operand layout (every wave is past the patch) ----
@@ -1339,6 +1433,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             for (int ks = 0; ks < KS2; ++ks) t2f[b][ks] = *(const uint4*)(tsm + row * ROWB + (((ks * 4 + fq) ^ sw) << 4));
         }
         __syncthreads();                                      // region A becomes the Y-chunk image
+        if constexpr (P1G) {                                  // ... and, for the generic conv_b, the home of the Wc buffers
+            FAV_T_STAGE_WC(0);
+            FAV_T_STAGE_WC(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     } else {
         // ---- conv_c alone: every wave reads the fragments of ITS rows straight from global memory (each byte of the
         //      tile is needed by one wave only, so an LDS round trip and its two barriers would buy nothing) ----------
@@ -1414,7 +1514,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             }
         }
         if (j + 1 < NCHUNK) {
-            if (WC2) FAV_T_STAGE_WC(j + 1);
+            if (BARQ == 2) {
+                if ((j & 1) == 0 && j + 2 < NCHUNK) { FAV_T_STAGE_WC(j + 2); FAV_T_STAGE_WC(j + 3); }
+            } else if (WC2) FAV_T_STAGE_WC(j + 1);
             if (NRED > 0) FAV_T_STAGE_WA(j + 1);
             FAV_T_LOAD_RES(j + 1)
         }
@@ -1522,7 +1624,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(acc3[NA3 - 1][TM2 - 1])); p.dbg[blockIdx.x * 16ull + 9] = __builtin_amdgcn_s_memtime(); }
         // the next chunk's weight pieces of this wave have landed (its residual loads and this chunk's stores stay in
         // flight), then the barrier publishes every wave's pieces and retires this chunk's reads of the current buffers
-        if (j + 1 < NCHUNK) {
+        if (j + 1 < NCHUNK && (BARQ == 1 || (j & 1))) {
             // WC2: the youngest operations are the next residual loads and this chunk's stores; otherwise the Wc pieces
             // were issued after the residual loads, so only the stores may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WC2 && HAS_RES) ? 4 * TM2 : 2 * TM2) : "memory");

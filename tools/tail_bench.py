@@ -13,6 +13,7 @@ SHAPES = [  # name, H, Cmid, Nred, has3x3
     ("L2 tail no3x3 128/512->128", 28, 128, 128, 0), ("L2 tail 3x3+c+a 128/512->128", 28, 128, 128, 1),
     ("L2 last tail 3x3+c 128/512", 28, 128, 0, 1),
     ("L3 conv_c alone 256/1024", 14, 256, 0, 0),
+    ("L3 3x3 + conv_c 256/1024", 14, 256, 0, 1),
     ("L3 conv_c + next reduce 256/1024->256", 14, 256, 256, 0),
 ]
 

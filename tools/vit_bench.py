@@ -1,5 +1,6 @@
-"""Throughput of the ViT-B/16 path (BASELINE configs[4] shape: 224x224, 64 frames per GPU = batch 512 over 8 GPUs)."""
-import argparse, json, os, sys, time
+"""ViT-B/16 (BASELINE configs[4], one GPU's share): frames/s of `classify` at a given batch; run it under
+`rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from failure_aware_vision_amd import Backend, synth, weights
@@ -7,24 +8,18 @@ from failure_aware_vision_amd import Backend, synth, weights
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--warmup", type=int, default=3)
 a = ap.parse_args()
-blob, info = weights.make_synthetic_vit("vit_b16", seed=1)
+blob, _ = weights.make_synthetic_vit("vit_b16", seed=1)
 be = Backend("vit_b16", blob, max_batch=a.batch, temperature=1.5, conf_kind="entropy")
-frames = torch.from_numpy(synth.gaussian_noise_f32(synth.synthetic_frames_u8(a.batch, 224, 224, seed=21), 3, seed=3)).cuda()
-for _ in range(a.warmup):
+frames = torch.from_numpy(synth.synthetic_frames_u8(a.batch, 224, 224, seed=21)).cuda()
+for _ in range(3):
     be.classify(frames)
-torch.cuda.synchronize()
-be.set_profiling(True)
-t0 = time.perf_counter()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
 for _ in range(a.steps):
-    labels, conf = be.classify(frames)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-prof = be.get_profile()
-gflop = 35.1   # per frame, SURVEY.md section 8d config 5
-fps = a.batch * a.steps / dt
-print(json.dumps({"workload": "ViT-B/16 224x224 single pass, entropy confidence (T=1.5), batch %d on 1 MI355X" % a.batch,
-                  "frames_per_s": fps, "ms_per_batch": 1e3 * dt / a.steps, "tflops_algorithmic": fps * gflop / 1e3,
-                  "kernel_ms_per_batch": {k: v["ms"] / a.steps for k, v in prof.items() if v["ms"] > 0},
-                  "labels_distinct": int(len(set(labels.cpu().tolist())))}))
+    be.classify(frames)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.steps
+gflop = 2 * (196 * 768 * 768 + 12 * (197 * 768 * (3 * 768 + 768 + 2 * 3072) + 2 * 12 * 197 * 197 * 64)) / 1e9
+print(f"vit_b16 batch {a.batch}: {ms:.3f} ms/call, {a.batch / ms * 1e3:.0f} frames/s, {a.batch * gflop / ms:.0f} TF/s "
+      f"({gflop:.1f} GFLOP/frame)")
