@@ -96,6 +96,8 @@ _SIGNATURES = {
                                  C.c_void_p]),
     "fav_op_entry_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(FavDropoutDesc),
                                        C.c_void_p]),
+    "fav_op_entry_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.POINTER(FavDropoutDesc), C.c_void_p]),
     "fav_op_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "fav_op_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

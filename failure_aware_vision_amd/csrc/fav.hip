@@ -70,7 +70,7 @@ struct Layer {  // one convolution / fc
     std::vector<float*> b_m;
 };
 
-enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT, OP_TAIL };
+enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT, OP_TAIL, OP_ENTRY_REDUCE };
 enum BufId { B_INPUT = -1, B_PHASE_IN = -2, B_PHASE_OUT = -3, B_NONE = -4, B_A1 = 5 };  // 0..4 rotating
 
 struct Op {
@@ -660,6 +660,31 @@ void launch_entry_dropout(fav_handle* h, const void* x, void* out, long long ele
                        elems / 16, n_out, dp);
 }
 
+// Entry dropout + the 1x1 reduce behind it (entry_reduce_kernel): 256 -> 64 channels, the first dropout site of the
+// all_blocks policy.  FAV_ENTRY_FUSE=0 keeps the two launches.
+bool entry_reduce_enabled() {
+    static const int on = [] { const char* e = getenv("FAV_ENTRY_FUSE"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+bool entry_reduce_supported(int C, int nred, long long n_img, long long HW) {
+    return C == 256 && nred == 64 && n_img * HW * C * 2 < 0x70000000LL;     // 32-bit byte offsets into the cached tensor
+}
+const char* launch_entry_reduce(fav_handle* h, const void* x, void* y, const void* wa, const float* bias_a, void* t1, int C, int nred,
+                                int HW, int n_out, const DropParams& dp, hipStream_t s) {
+    if (!entry_reduce_supported(C, nred, dp.n_img, HW)) return "entry reduce: unsupported shape";
+    if (dp.site < 0 || n_out < 1 || dp.v0 < 0 || dp.v0 + n_out > 0x7fffffffLL) return "entry reduce: bad dropout descriptor";
+    EntryReduceParams p;
+    p.x = (const uint16_t*)x; p.y = (uint16_t*)y; p.wa = (const uint16_t*)wa; p.bias_a = bias_a; p.t1 = (uint16_t*)t1;
+    p.HW = HW; p.M = (int)((long long)dp.n_img * HW); p.n_out = n_out;
+    p.drop = dp;
+    p.div_hw = fastdiv_make((uint32_t)HW);
+    const long long cached = std::min<long long>(dp.n_img, n_out);
+    const double rows = (double)n_out * HW;
+    Prof pr(h, s, FAV_K_CONV, 2.0 * rows * C * nred, 2.0 * ((double)cached * HW * C + rows * (C + nred) + (double)C * nred));
+    hipLaunchKernelGGL((entry_reduce_kernel<256, 64>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
+    return nullptr;
+}
+
 const char* launch_head(fav_handle* h, const float* logits, int T, int n, int C, int ld, float temperature, int kind,
                         float tau, int* labels, float* conf, uint8_t* fail, float* score, hipStream_t s) {
     if (C > 1024 || C < 1) return "head: num_classes must be in [1, 1024]";
@@ -925,6 +950,24 @@ fav_status build_graph(fav_handle* h) {
         ed.out = h->ops[split - 1].out;
         h->ops.insert(h->ops.begin() + split, ed);
         regroup_now = regroup_op >= split ? regroup_op + 1 : regroup_op;
+        // the 1x1 reduce that follows (the next block's conv1) joins the dropout launch when both lie in one phase
+        if (split + 2 < (int)h->ops.size() && split + 1 != regroup_now && tail_enabled() && entry_reduce_enabled() && !h->plan_no_fuse &&
+            c.math_mode == FAV_MATH_BF16) {
+            const Op& cv = h->ops[split + 1];
+            const Op& e0 = h->ops[split];
+            if (cv.kind == OP_CONV && cv.in == e0.out && cv.res == B_NONE && cv.relu == 1 && !cv.out_f32 && cv.out != e0.out && cv.site < 0) {
+                const Layer& L = h->layers[cv.layer];
+                if (L.kh == 1 && L.kw == 1 && L.stride == 1 && L.pad == 0 && L.cout == L.cout_pad &&
+                    entry_reduce_supported(L.cin, L.cout, c.max_batch, (long long)cv.H * cv.W)) {
+                    Op f = e0;
+                    f.kind = OP_ENTRY_REDUCE; f.layer_a = cv.layer; f.out2 = cv.out; f.Co2 = L.cout;
+                    f.H = cv.H; f.W = cv.W; f.C = L.cin; f.relu = 1;
+                    h->ops[split] = f;
+                    h->ops.erase(h->ops.begin() + split + 1);
+                    if (regroup_now > split + 1) --regroup_now;
+                }
+            }
+        }
         const int nops = (int)h->ops.size();
         // split the suffix only if at least one real op lies on each side
         if (split + 1 < regroup_now && regroup_now < nops) { add_phase(split, regroup_now, true); add_phase(regroup_now, nops, true); }
@@ -937,8 +980,9 @@ fav_status build_graph(fav_handle* h) {
         if (first.kind != OP_STEM_IM2COL) {
             // consumers of the phase input: every op in the phase reading the buffer the
             // previous phase's last op wrote, until that rotating buffer is overwritten
-            const int src = (first.kind == OP_ENTRY_DROPOUT) ? B_PHASE_IN : first.in;
-            if (first.kind != OP_ENTRY_DROPOUT) {
+            const bool entry = first.kind == OP_ENTRY_DROPOUT || first.kind == OP_ENTRY_REDUCE;
+            const int src = entry ? B_PHASE_IN : first.in;
+            if (!entry) {
                 for (int k = p.op_begin; k < p.op_end; ++k) {
                     Op& o = h->ops[k];
                     if (o.in == src) o.in = B_PHASE_IN;
@@ -1148,6 +1192,13 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                 case OP_ENTRY_DROPOUT: {
                     DropParams dp = make_drop(&dd);
                     launch_entry_dropout(h, pin_base, buf(o.out, true, o), o.in_elems, cn, dp, s);
+                    break;
+                }
+                case OP_ENTRY_REDUCE: {
+                    DropParams dp = make_drop(&dd);
+                    const Layer& La = h->layers[o.layer_a];
+                    if (const char* e = launch_entry_reduce(h, pin_base, buf(o.out, true, o), La.w, La.b, buf(o.out2, true, o), o.C, o.Co2,
+                                                            o.H * o.W, cn, dp, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
                     break;
                 }
             }
@@ -1633,6 +1684,7 @@ fav_status fav_set_profiling(fav_handle* h, int32_t enable) {
         r.H = o.H; r.W = o.W; r.Cin = o.C; r.Ho = o.Ho; r.Wo = o.Wo; r.Cout = o.Co;
         r.kh = r.kw = r.stride = 0;
         if (o.layer >= 0) { const Layer& L = h->layers[o.layer]; r.kh = L.kh; r.kw = L.kw; r.stride = L.stride; }
+        if (o.kind == OP_ENTRY_REDUCE) { r.reserved = o.Co2; r.kh = r.kw = r.stride = 1; r.Ho = o.H; r.Wo = o.W; r.Cout = o.C; }
         if (o.kind == OP_TAIL) { r.reserved = o.Co2; if (o.layer < 0) { r.kh = r.kw = r.stride = 1; } }   // reserved: channels of the fused next-block conv1
     }
     return FAV_OK;
@@ -1699,6 +1751,12 @@ fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t
     if (!x || !y || C % 16 != 0 || HW < 1) return op_done("fav_op_avgpool: bad argument");
     launch_avgpool(nullptr, x, y, n, HW, C, make_drop(drop), (hipStream_t)stream);
     return op_done(nullptr);
+}
+
+fav_status fav_op_entry_reduce(const void* x, void* y, const void* wa, const float* bias_a, void* t1, int32_t C, int32_t Nred,
+                               int32_t HW, int32_t n_out, const fav_dropout_desc* drop, void* stream) {
+    if (!x || !y || !wa || !bias_a || !t1 || !drop || drop->site < 0 || HW < 1) return op_done("fav_op_entry_reduce: bad argument");
+    return op_done(launch_entry_reduce(nullptr, x, y, wa, bias_a, t1, C, Nred, HW, n_out, make_drop(drop), (hipStream_t)stream));
 }
 
 fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems, int32_t n_out, const fav_dropout_desc* drop, void* stream) {

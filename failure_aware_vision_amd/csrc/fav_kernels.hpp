@@ -1786,6 +1786,168 @@ __global__ __launch_bounds__(256) void entry_dropout_kernel(const uint4* __restr
 }
 
 // ---------------------------------------------------------------------------
+// Entry dropout + the first 1x1 reduce behind it, one launch:
+//   y[v - v0]  = dropout_{t, frame}(x[v % n_img])                      (what entry_dropout_kernel writes)
+//   t1[v - v0] = bf16(relu(conv1x1(y[v - v0], Wa) + bias_a))           (the next block's conv1, C -> NRED)
+// Layer by layer the reduce reads all of y back (12.3 GB per step of the headline); here a block keeps 128 pixels
+// of the CACHED tensor in registers - in the epilogue layout of bottleneck_tail_kernel, lane (pixel frow, quad fq)
+// holds channels 64j + 16fq .. + 15 of its pixels - and walks over the samples t of the chunk: one Philox call per
+// 16 channels, y stored straight from registers, the same 16 channels written to the wave's own rows of a
+// 64-channel LDS image and multiplied with the resident Wa (k ascending in 64-channel chunks, two 32-deep MFMA
+// steps each: the order conv_igemm_kernel uses, so t1 is bit-identical to the separate launches).  No global load
+// and no workgroup barrier inside the sample loop; the cached tensor is read once, not once per sample.
+// ---------------------------------------------------------------------------
+struct EntryReduceParams {
+    const uint16_t* x;        // cached prefix output [n_img][HW][C]
+    uint16_t* y;              // [n_out][HW][C]
+    const uint16_t* wa; const float* bias_a;     // [NRED][C]
+    uint16_t* t1;             // [n_out][HW][NRED]
+    int HW, M, n_out;         // M = n_img * HW pixels of the cached tensor
+    DropParams drop;
+    FastDiv div_hw;
+};
+
+template <int C, int NRED>
+__global__ __launch_bounds__(256, 3) void entry_reduce_kernel(const EntryReduceParams p) {
+    constexpr int NW = 4, BM = 32 * NW, TM2 = 2, NJ = C / 64, NA3 = NRED / 16, G3 = NRED / 64;
+    constexpr int WA_BYTES = NRED * 128;                  // one 64-k chunk of Wa: NRED rows x 128 B
+    constexpr int WA_PW = WA_BYTES / 1024 / NW;           // LDS-DMA pieces per wave per chunk
+    static_assert(WA_BYTES % (1024 * NW) == 0 && NRED % 64 == 0 && C % 64 == 0, "tile shape");
+    // [Wa: NJ chunks | Y chunk image [BM][64] | bias (16-channel chunks 20 floats apart)]
+    __shared__ __attribute__((aligned(16))) unsigned char esm[NJ * WA_BYTES + BM * 128 + NRED * 5];
+    unsigned char* const ych = esm + NJ * WA_BYTES;
+    float* const bias_s = (float*)(esm + NJ * WA_BYTES + BM * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    for (int i = tid; i < NRED; i += 256) bias_s[(i >> 4) * 20 + (i & 15)] = p.bias_a[i];
+    // ---- Wa -> LDS (rows in the order tail_row_perm gives, 16-B chunks XOR (row & 7)), once per block ----
+    {
+        const uint32_t lds_base =
+            __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)esm);
+        const __amdgpu_buffer_rsrc_t srd_wa = __builtin_amdgcn_make_buffer_rsrc((void*)p.wa, 0, NRED * C * 2, 0x00020000);
+        const int wrow = lane >> 3, wch = (lane & 7) ^ (wrow & 7);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < WA_PW; ++i) {
+                const int pc = wave_u + i * NW;
+                lds_dma16(srd_wa, (uint32_t)((tail_row_perm(pc * 8 + wrow) * C + wch * 8) * 2), (uint32_t)(j * 128),
+                          __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(j * WA_BYTES + pc * 1024)));
+            }
+    }
+    // ---- this wave's 32 pixels of the cached tensor, epilogue layout ----
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)p.M * (uint32_t)(C * 2), 0x00020000);
+    u32x4_t xr[TM2][NJ][2];
+    uint32_t img[TM2], pix[TM2], moff[TM2];
+#pragma unroll
+    for (int b = 0; b < TM2; ++b) {
+        const uint32_t m = (uint32_t)(m0 + wave * 32 + b * 16 + frow);
+        img[b] = fastdiv(m, p.div_hw);
+        pix[b] = m - img[b] * (uint32_t)p.HW;
+        moff[b] = m < (uint32_t)p.M ? m : 0x7fffffffu / (uint32_t)(C * 2);      // beyond the tensor: loads read zeros, stores are dropped
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int off = (int)(moff[b] * (uint32_t)(C * 2)) + (j * 64 + fq * 16) * 2;
+            xr[b][j][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, off, 0, 0);
+            xr[b][j][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, off + 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const long long v_end = p.drop.v0 + p.n_out;
+    const int t_lo = (int)(p.drop.v0 / p.drop.n_img), t_hi = (int)((v_end - 1) / p.drop.n_img);
+    for (int t = t_lo; t <= t_hi; ++t) {
+        // rows of sample t: virtual frame v = t * n_img + img; its output row block starts (v - v0) * HW pixels into y / t1
+        const long long sample0 = ((long long)t * p.drop.n_img - p.drop.v0) * p.HW;      // may be negative for a chunk's first sample
+        const __amdgpu_buffer_rsrc_t srd_y =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + sample0 * C), 0, (uint32_t)p.M * (uint32_t)(C * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_t =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + sample0 * NRED), 0, (uint32_t)p.M * (uint32_t)(NRED * 2), 0x00020000);
+        uint32_t orow[TM2];
+#pragma unroll
+        for (int b = 0; b < TM2; ++b) {
+            const long long v = (long long)t * p.drop.n_img + img[b];
+            orow[b] = (v >= p.drop.v0 && v < v_end) ? moff[b] : 0x7fffffffu / (uint32_t)(C * 2);
+        }
+        f32x4_t acc3[NA3][TM2];
+#pragma unroll
+        for (int a = 0; a < NA3; ++a)
+#pragma unroll
+            for (int b = 0; b < TM2; ++b) acc3[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int b = 0; b < TM2; ++b) {
+                const int row = wave * 32 + b * 16 + frow;
+                const uint32_t chunk = pix[b] * (uint32_t)(C / 16) + (uint32_t)(4 * j + fq);
+                const uint4 w4 = drop_draws16_ti(p.drop, (uint32_t)t, img[b], chunk);
+                const uint32_t draws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t w = xr[b][j][g][k];
+                        const float lo = FAV_DROP_APPLY(bf16_bits_to_f32(w & 0xFFFFu), draws, 8 * g + 2 * k, p.drop);
+                        const float hi = FAV_DROP_APPLY(bf16_bits_to_f32(w >> 16), draws, 8 * g + 2 * k + 1, p.drop);
+                        o[k] = pack_bf16x2(lo, hi);
+                    }
+                    const u32x4_t ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, srd_y, (int)(orow[b] * (uint32_t)(C * 2)) + (j * 64 + fq * 16 + 8 * g) * 2, 0, 0);
+                    *(u32x4_t*)(ych + row * 128 + (((2 * fq + g) ^ (row & 7)) << 4)) = ov;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned char* const wab = esm + j * WA_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 fy[TM2];
+#pragma unroll
+                for (int b = 0; b < TM2; ++b) {
+                    const int row = wave * 32 + b * 16 + frow;
+                    fy[b] = *(const uint4*)(ych + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < NA3; ++a) {
+                    const int row = a * 16 + frow;
+                    union { uint4 u; bf16x8_t v; } ua;
+                    ua.u = *(const uint4*)(wab + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+#pragma unroll
+                    for (int b = 0; b < TM2; ++b) {
+                        union { uint4 u; bf16x8_t v; } ub;
+                        ub.u = fy[b];
+                        acc3[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc3[a][b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // t1 = bf16(relu(acc3 + bias)): lane holds channels 64*g3 + 16fq .. + 15 of its pixel rows
+#pragma unroll
+        for (int g3 = 0; g3 < G3; ++g3) {
+            float bia[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *(const float4*)(bias_s + (g3 * 4 + fq) * 20 + 4 * q);
+                bia[4 * q] = bq.x; bia[4 * q + 1] = bq.y; bia[4 * q + 2] = bq.z; bia[4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int b = 0; b < TM2; ++b)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(__fadd_rn(acc3[g3 * 4 + 2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]), 0.f);
+                    const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, srd_t, (int)(orow[b] * (uint32_t)(NRED * 2)) + (g3 * 64 + fq * 16 + 8 * g) * 2, 0, 0);
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // ViT kernels (BASELINE configs[4]).
 // ---------------------------------------------------------------------------
 // Token assembly: x[f][0] = pos[0] (class token folded in), x[f][1+p] = bf16(emb[f*np + p] + pos[1+p]).

@@ -142,7 +142,7 @@ typedef struct fav_profile {
 } fav_profile;
 /* One row per op of the static schedule (valid after fav_get_profile). */
 typedef struct fav_op_profile {
-    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout, 5 fused bottleneck tail */
+    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout, 5 fused bottleneck tail, 6 entry dropout + reduce */
     int32_t H, W, Cin, Ho, Wo, Cout, kh, kw, stride;
     int32_t reserved;
     double ms, flops, bytes;
@@ -203,6 +203,11 @@ fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t
 /* out[v - v0][e] = dropout(x[v % n_img][e]) for v in [v0, v0 + n_out) */
 fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems_per_frame, int32_t n_out,
                                 const fav_dropout_desc* drop, void* hip_stream);
+/* entry dropout and the 1x1 reduce behind it in one launch (C = 256, Nred = 64):
+ * y[v - v0] = dropout(x[v % n_img]) as above, t1[v - v0] = bf16(relu(conv1x1(y[v - v0], wa) + bias_a)); x [n_img][HW][C],
+ * wa [Nred][C] bf16.  The executor's fusion of the MC-Dropout suffix's first two launches (no reference counterpart). */
+fav_status fav_op_entry_reduce(const void* x, void* y, const void* wa, const float* bias_a, void* t1, int32_t C, int32_t Nred,
+                               int32_t HW, int32_t n_out, const fav_dropout_desc* drop, void* hip_stream);
 /* logits fp32 [T][n][ld] -> labels, conf (and fail/score if non-NULL) */
 fav_status fav_op_head(const float* logits, int32_t T, int32_t n, int32_t num_classes, int32_t ld,
                        float temperature, int32_t conf_kind, float tau,

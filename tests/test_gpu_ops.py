@@ -204,6 +204,58 @@ def test_entry_dropout_exact(lib):
     assert np.array_equal(host_f32(out), ref)
 
 
+@pytest.mark.parametrize("n_img,H,W,v0,n_out", [(3, 7, 9, 2, 7),        # partial first and last sample, tiles span frames
+                                                 (5, 14, 14, 0, 15),     # three whole samples, ragged last tile (M = 980)
+                                                 (2, 56, 56, 1, 2),      # layer-1 frames, window inside the samples
+                                                 (9, 5, 3, 4, 1)])       # a single virtual frame
+def test_entry_reduce_bitwise_vs_separate_launches_and_oracle(lib, n_img, H, W, v0, n_out):
+    """Entry dropout + the 1x1 reduce behind it in one launch (entry_reduce_kernel): y and t1 bit-identical to
+    fav_op_entry_dropout followed by fav_op_conv2d, and to the oracle (Philox masks, MFMA-model accumulation)."""
+    rng = np.random.default_rng(n_img * 100 + H + v0)
+    Cc, nred, HW = 256, 64, H * W
+    x = O.bf16_round(np.maximum(rng.standard_normal((n_img, H, W, Cc)) * np.exp2(rng.integers(-2, 3, (n_img, H, W, Cc))), -0.1).astype(np.float32))
+    wa = O.bf16_round((rng.standard_normal((nred, 1, 1, Cc)) * np.sqrt(2.0 / Cc)).astype(np.float32))
+    ba = (rng.standard_normal(nred) * 0.2).astype(np.float32)
+    thr = O.dropout_threshold(0.1)
+    scale = O.dropout_scale(thr)
+    d = drop_desc(1, thr, float(scale), 77, v0, n_img, 40)
+    xd, wd, bd = dev_bf16(x), dev_bf16(wa), torch.from_numpy(ba).cuda()
+    y = torch.zeros((n_out, H, W, Cc), dtype=torch.bfloat16, device="cuda")
+    t1 = torch.zeros((n_out, H, W, nred), dtype=torch.bfloat16, device="cuda")
+    guard = 4096                                                   # rows outside the window must stay untouched
+    ybig = torch.full((n_out * HW * Cc + 2 * guard,), 3.0, dtype=torch.bfloat16, device="cuda")
+    tbig = torch.full((n_out * HW * nred + 2 * guard,), 3.0, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.fav_op_entry_reduce(xd.data_ptr(), ybig.data_ptr() + 2 * guard, wd.data_ptr(), bd.data_ptr(), tbig.data_ptr() + 2 * guard,
+                                       Cc, nred, HW, n_out, C.byref(d), None))
+    torch.cuda.synchronize()
+    for big in (ybig, tbig):
+        assert bool((big[:guard] == 3.0).all()) and bool((big[-guard:] == 3.0).all())
+    y = host_f32(ybig[guard:-guard].reshape(n_out, H, W, Cc))
+    t1 = host_f32(tbig[guard:-guard].reshape(n_out, H, W, nred))
+    # (a) the separate launches
+    y2 = torch.empty((n_out, HW * Cc), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.fav_op_entry_dropout(xd.data_ptr(), y2.data_ptr(), HW * Cc, n_out, C.byref(d), None))
+    torch.cuda.synchronize()
+    y_ref = host_f32(y2).reshape(n_out, H, W, Cc)
+    t1_ref = run_conv(lib, y_ref, wa, ba, None, 1, 0, relu=1)
+    assert np.array_equal(y, y_ref), f"y: {np.mean(y != y_ref):.5f} of elements differ"
+    assert np.array_equal(t1, t1_ref), f"t1: {np.mean(t1 != t1_ref):.5f} of elements differ"
+    # (b) the oracle
+    oy = np.empty_like(y)
+    for i in range(n_out):
+        v = v0 + i
+        keep = O.dropout_keep(77, v // n_img, 1, np.array([40 + v % n_img]), HW * Cc, thr)[0].reshape(H, W, Cc)
+        oy[i] = O.bf16_round(np.where(keep, x[v % n_img] * scale, 0).astype(np.float32))
+    assert np.array_equal(y, oy)
+    assert np.array_equal(t1, O.epilogue(O.conv_acc_exact(oy, wa, 1, 1, 1, 0, mode="mfma"), ba))
+
+
+def test_entry_reduce_rejects_unsupported_shapes(lib):
+    x = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    d = drop_desc(1, 26, 1.1, 7, 0, 1, 0)
+    assert lib.fav_op_entry_reduce(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 128, 64, 4, 1, C.byref(d), None) == 1
+
+
 @pytest.mark.parametrize("T,n,Cc,ld", [(1, 5, 1000, 1024), (30, 9, 1000, 1024), (3, 4, 10, 64), (7, 3, 257, 320)])
 def test_head_vs_oracle(lib, T, n, Cc, ld):
     rng = np.random.default_rng(T * 100 + Cc)

@@ -345,6 +345,10 @@ def _replay(ops):
             wr(o["out"], ("avgpool", x, o["site"]))
         elif k == 4:
             wr(o["out"], ("entry_dropout", o["site"], x))
+        elif k == 6:                  # entry dropout + the 1x1 reduce behind it
+            y = ("entry_dropout", o["site"], x)
+            wr(o["out"], y)
+            wr(o["out2"], ("conv", o["la"], y, None, 1, -1))
         elif k == 5:
             t2 = ("conv", o["layer"], x, None, 1, -1) if o["layer"] >= 0 else x
             y = ("conv", o["lc"], t2, r, 1, o["site"])
@@ -385,6 +389,6 @@ def test_fused_schedule_computes_the_layer_by_layer_dataflow(lib):
     tails = [o for o in ops if o["kind"] == 5]
     assert len(tails) == 13 and sum(o["la"] >= 0 for o in tails) == 5
     assert sum(o["layer"] >= 0 for o in tails) == 11     # conv_b inside the tail: layers 1-2 (6) and layer 3's five identity blocks
-    assert sum(o["kind"] == 4 for o in ops) == 1 and len({o["phase"] for o in ops}) == 3
+    assert sum(o["kind"] == 6 for o in ops) == 1 and not any(o["kind"] == 4 for o in ops) and len({o["phase"] for o in ops}) == 3
     # the validation mode keeps the separate launches
     assert not any(o["kind"] == 5 for o in _plan(lib, 1, 0, math_mode=1))
