@@ -452,10 +452,23 @@ struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2, rp; };
 // / 256-pixel variant measured the same, profiles/r2a_tail_bench.txt); 128 mid channels: 8 waves (256 pixels, one block
 // per CU); 256 (conv_c alone): 4 waves, two blocks per CU.
 inline int tail_nw(int cmid) { return cmid == 128 ? 8 : 4; }
+// 512 mid channels (layer 4): the expanding 1x1 + residual + dropout on the row-owning structure.  FAV_TAIL_L4=0 disables.
+bool tail_l4() {
+    static const int on = [] { const char* e = getenv("FAV_TAIL_L4"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     // 256 mid channels (layer 3): the expanding 1x1 alone, or with the next block's reduce (then 8 waves x 16 rows)
-    if (cmid == 256) { if ((has3x3 && nred != 0) || !(nred == 0 || nred == 256)) return false; }
+    if (cmid == 512) {      // layer 4: the expanding 1x1 alone
+        if (has3x3 || nred != 0) return false;
+        // 8 waves x 32 pixels, Wc double-buffered (2 x 64 KB), one block per CU: 1.14 ms against 1.24 ms for 4 waves with a
+        // single Wc buffer at two blocks per CU and 1.27 ms for the generic kernel (profiles/r2j_tail_l4.txt)
+        g->patch_bytes = 0; g->rega_bytes = 0; g->nw = 8; g->rp = 32; g->wc2 = 1;
+        g->lds_bytes = 2 * 65536 + (cmid + 4 * cmid) * 5 + 16;
+        return true;
+    }
+    else if (cmid == 256) { if ((has3x3 && nred != 0) || !(nred == 0 || nred == 256)) return false; }
     else if ((cmid != 64 && cmid != 128) || !(nred == 0 || nred == cmid || nred == 128)) return false;
     if (cmid == 256 && has3x3) {
         // conv_b as the generic 256 x 256 x 64 loop (two 64 KB stages); T2, then the Wc buffers, reuse those 128 KB
@@ -503,6 +516,7 @@ bool tail_wide3x3() {
     return on != 0;
 }
 
+// 512 mid channels (layer 4): the expanding 1x1 + residual + dropout on the row-owning structure.  FAV_TAIL_L4=0 disables.
 bool tail_enabled() {
     static const int on = [] { const char* e = getenv("FAV_FUSE"); return e ? atoi(e) : 1; }();
     return on != 0;
@@ -580,6 +594,8 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     } else if (cmid == 128) {
         if (has3x3) { if (nred == 0) FAV_TAIL_W(128, 0, true, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, true, 2, 8); }
         else { if (nred == 0) FAV_TAIL_W(128, 0, false, 2, 8); if (nred == 128) FAV_TAIL_W(128, 128, false, 2, 8); }
+    } else if (cmid == 512) {
+        FAV_TAIL(512, 0, false, 2, 8, true);
     } else if (nred == 0 && has3x3) {
         FAV_TAIL(256, 0, true, 2, 8, true);
     } else if (nred == 0) {
@@ -836,9 +852,14 @@ fav_status build_graph(fav_handle* h) {
                 const int next_pl = (bi + 1 < A.depths[st]) ? pl : (st < 3 ? A.planes[st + 1] : 0);
                 int nred = boundary_after ? 0 : next_pl;
                 TailGeom tg;
-                const bool tail_3x3 = (s == 1) && (pl <= 128 || (pl == 256 && tail_wide3x3()));
+                // the 256-pixel / 8-wave kernels of layers 3-4 run one block per CU: they pay only when the planned launch
+                // (max_batch frames, x T samples behind the first dropout site) brings two blocks per CU
+                const long long plan_rows = (long long)c.max_batch * ((mc_first_site >= 0 && bidx > mc_first_site) ? c.n_samples : 1) * Hn * Wn;
+                const char* min_rows_env = getenv("FAV_TAIL_MIN_ROWS");        // tests: 0 forces those kernels at any size
+                const bool big_launch = plan_rows >= (min_rows_env ? atoll(min_rows_env) : 512ll * 256);
+                const bool tail_3x3 = (s == 1) && (pl <= 128 || (pl == 256 && tail_wide3x3() && big_launch));
                 if (pl > 128 && (nred != pl || !tail_wide_reduce())) nred = 0;   // wide blocks: the expanding 1x1 (+ the next reduce inside a stage)
-                bool fuse = tail_enabled() && !h->plan_no_fuse && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()));
+                bool fuse = tail_enabled() && !h->plan_no_fuse && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()) || (pl == 512 && tail_l4() && big_launch));
                 if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {
                     nred = 0;
                     fuse = tail_geometry(pl, 0, tail_3x3, Wn, &tg);

@@ -46,14 +46,24 @@ def frame_crc(lg):
     return np.array([zlib.crc32(np.ascontiguousarray(lg[:, i, :]).tobytes()) for i in range(lg.shape[1])], np.uint32)
 
 
-def test_production_mode_mc_dropout_t30_fixture(r50_blob):
+@pytest.mark.parametrize("min_rows", [None, "0"])
+def test_production_mode_mc_dropout_t30_fixture(r50_blob, monkeypatch, min_rows):
     """BASELINE configs[2] (T=30, all_blocks, p=0.1, noise severity 3) in PRODUCTION bf16 mode:
-    all 30 x 1000 logits of every frame bit-identical to the MFMA-model oracle."""
+    all 30 x 1000 logits of every frame bit-identical to the MFMA-model oracle.  FAV_TAIL_MIN_ROWS=0 plans the 16-frame
+    batch like the 256-frame headline (layer 3's conv_b + conv_c launch and layer 4's row-owning expand, which the
+    executor otherwise keeps for launches that fill the chip)."""
     blob, info = r50_blob
     d = load("r50_mfma_mc30_16.npz", info)
     n = len(d["labels"])
+    if min_rows is not None:
+        monkeypatch.setenv("FAV_TAIL_MIN_ROWS", min_rows)
     be = Backend("resnet50", blob, max_batch=n, n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    be.set_profiling(True)
     labels, conf = be.classify(frames(0, n))
+    rows = be.get_op_profile()
+    wide = [r for r in rows if r["kind"] == 5 and ((r["Cin"] == 256 and r["kh"] == 3) or r["Cin"] == 512)]
+    assert len(wide) == (8 if min_rows == "0" else 0)           # layer 3's five identity blocks + layer 4's three expands
+    assert sum(r["kind"] == 6 for r in rows) == 1                # entry dropout + reduce, one launch
     assert np.array_equal(frame_crc(be.logits()), d["logit_crc32"])
     tie = d["gap"] < 1e-6
     assert np.array_equal(labels.cpu().numpy()[~tie], d["labels"].astype(np.int32)[~tie])

@@ -58,6 +58,8 @@ CASES = [
     (256, 0, False, 7, 9, 3),
     (256, 256, False, 14, 14, 11),  # layer 3 inner boundary: expand + the next block's reduce, 8 waves x 16 rows
     (256, 256, False, 5, 7, 9),
+    (512, 0, False, 7, 7, 45),      # layer 4's expanding 1x1 alone (single Wc buffer of 64 KB); M = 2205 (ragged)
+    (512, 0, False, 8, 10, 3),
     (256, 0, True, 14, 14, 11),     # layer 3: conv_b as the generic 256x256x64 loop + conv_c in one launch; M = 2156 (ragged)
     (256, 0, True, 7, 9, 5),        # frames much smaller than a tile
     (256, 0, True, 15, 20, 2),      # the 240x320 seam at layer 3 (H != W)

@@ -387,7 +387,7 @@ def test_fused_schedule_computes_the_layer_by_layer_dataflow(lib):
     # the headline configuration: which ops it consists of
     ops = _plan(lib, 1, 0, site_mask=weights.site_mask_for(1, "all_blocks"), n_samples=30, dropout_p=0.1)
     tails = [o for o in ops if o["kind"] == 5]
-    assert len(tails) == 13 and sum(o["la"] >= 0 for o in tails) == 5
+    assert len(tails) == 16 and sum(o["la"] >= 0 for o in tails) == 5      # every bottleneck of the suffix ends in a fused tail
     assert sum(o["layer"] >= 0 for o in tails) == 11     # conv_b inside the tail: layers 1-2 (6) and layer 3's five identity blocks
     assert sum(o["kind"] == 6 for o in ops) == 1 and not any(o["kind"] == 4 for o in ops) and len({o["phase"] for o in ops}) == 3
     # the validation mode keeps the separate launches

@@ -14,6 +14,7 @@ SHAPES = [  # name, H, Cmid, Nred, has3x3
     ("L2 last tail 3x3+c 128/512", 28, 128, 0, 1),
     ("L3 conv_c alone 256/1024", 14, 256, 0, 0),
     ("L3 3x3 + conv_c 256/1024", 14, 256, 0, 1),
+    ("L4 conv_c alone 512/2048", 7, 512, 0, 0),
     ("L3 conv_c + next reduce 256/1024->256", 14, 256, 256, 0),
 ]
 
