@@ -270,11 +270,12 @@ bool proj_enabled() {
 }
 
 bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
-    if (!proj_enabled() || d.kh != 1 || d.kw != 1 || d.pad != 0 || d.Cin != 256 || d.Cout != 512 || d.res || d.drop.site >= 0 || d.out_f32 ||
-        d.relu != 0 || d.math_mode != FAV_MATH_BF16 || (d.stride != 1 && d.stride != 2)) return false;
+    const bool wide = d.Cin == 512 && d.Cout == 1024;       // layer 3's shortcut: 8 waves x 32 pixels, one block per CU
+    if (!proj_enabled() || d.kh != 1 || d.kw != 1 || d.pad != 0 || !((d.Cin == 256 && d.Cout == 512) || wide) || d.res || d.drop.site >= 0 ||
+        d.out_f32 || d.relu != 0 || d.math_mode != FAV_MATH_BF16 || (d.stride != 1 && d.stride != 2)) return false;
     const int Ho = conv_out(d.H, 1, d.stride, 0), Wo = conv_out(d.W, 1, d.stride, 0);
     const long long M = (long long)d.n_frames * Ho * Wo;
-    if (M < 4096 || M > 0x7fffffffLL || (long long)d.H * d.W * 512 * 4 >= 0x40000000LL) return false;
+    if (M < (wide ? 512 * 256 : 4096) || M > 0x7fffffffLL || (long long)d.H * d.W * d.Cin * 2 * 4 >= 0x40000000LL) return false;
     TailParams p;
     memset(&p, 0, sizeof p);
     p.t1 = (const uint16_t*)d.x; p.wc = (const uint16_t*)d.w; p.bias_c = d.bias; p.y = (uint16_t*)d.y;
@@ -285,17 +286,20 @@ bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
     p.div_hw = fastdiv_make((uint32_t)p.HW);
     p.div_w = fastdiv_make((uint32_t)Wo);
     p.dbg = nullptr;
-    const int lds = 2 * 64 * 512 + (256 + 512) * 5 + 16;
+    const int lds = 2 * 64 * d.Cin * 2 + (d.Cin + d.Cout) * 5 + 16;
     auto kern = bottleneck_tail_kernel<256, 0, false, 2, 4, true, 32, 512, false, false>;
+    auto kern_w = bottleneck_tail_kernel<512, 0, false, 2, 8, true, 32, 1024, false, false>;
     static DeviceFlags attr_set;
     if (!attr_set.test_current()) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)kern_w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.set_current();
     }
-    const double flops = 2.0 * (double)M * 256.0 * 512.0;
-    const double bytes = 2.0 * ((double)M * (256 + 512) + 256.0 * 512.0);
+    const double flops = 2.0 * (double)M * d.Cin * d.Cout;
+    const double bytes = 2.0 * ((double)M * (d.Cin + d.Cout) + (double)d.Cin * d.Cout);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), lds, s, p, 0);
+    if (wide) hipLaunchKernelGGL(kern_w, dim3((unsigned)((M + 255) / 256)), dim3(512), lds, s, p, 0);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), lds, s, p, 0);
     return true;
 }
 

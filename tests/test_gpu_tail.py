@@ -123,3 +123,28 @@ def test_projection_shortcut_on_the_row_owning_kernel(lib, stride, H, W, n):
     ref = O.epilogue(O.conv_acc_exact(x, w, 1, 1, stride, 0, mode="mfma"), b, relu=False)
     assert got.shape == ref.shape and got.shape[0] * got.shape[1] * got.shape[2] >= 4096
     assert np.array_equal(got, ref), f"{np.mean(got != ref):.5f} of elements differ"
+
+
+@pytest.mark.parametrize("stride,H,W,n", [(2, 28, 28, 672), (1, 14, 14, 700)])
+def test_wide_projection_shortcut_on_the_row_owning_kernel(lib, stride, H, W, n):
+    """1x1 / stride s, 512 -> 1024 (layer 3's projection shortcut) takes the 8-wave row-owning kernel once the launch
+    brings two blocks per CU (M >= 131 072 output pixels).  Tensors are made on the device (the input is 0.5 GB);
+    the whole output is compared with the generic kernel (its fp32 output, rounded here: same accumulation, same
+    rounding point) and the first / last frames with the MFMA-model oracle."""
+    g = torch.Generator(device="cuda").manual_seed(stride * 1000 + n)
+    x = (torch.randn((n, H, W, 512), device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    w = (torch.randn((1024, 1, 1, 512), device="cuda", generator=g) * (1.0 / 512) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(1024, device="cuda", generator=g) * 0.2
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert n * Ho * Wo >= 131072
+    y = torch.zeros((n, Ho, Wo, 1024), dtype=torch.bfloat16, device="cuda")
+    yf = torch.zeros((n, Ho, Wo, 1024), dtype=torch.float32, device="cuda")
+    for out, f32 in ((y, 0), (yf, 1)):
+        d = _lib.FavConvDesc(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), n, H, W, 512, 1024, 1, 1, stride, 0, 0, f32, 0, drop_desc())
+        _lib.check(lib.fav_op_conv2d(C.byref(d), None))
+    torch.cuda.synchronize()
+    assert torch.equal(y, yf.to(torch.bfloat16)), "row-owning kernel differs from the generic kernel"
+    for sl in (slice(0, 3), slice(n - 3, n)):
+        xs, ws = x[sl].float().cpu().numpy(), w.float().cpu().numpy()
+        ref = O.epilogue(O.conv_acc_exact(xs, ws, 1, 1, stride, 0, mode="mfma"), b.cpu().numpy(), relu=False)
+        assert np.array_equal(y[sl].float().cpu().numpy(), ref)
