@@ -327,9 +327,13 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     if (p.drop.site >= 0 && (p.drop.v0 < 0 || p.drop.v0 + d.n_frames > 0x7fffffffLL)) return "conv: virtual frame index out of range";
     p.dbg = nullptr;
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
-    const bool big = conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
+    // the ViT encoder's GEMMs (M = 197 rows per frame, K = 768 / 3072, 64 frames per call): measured on MI355X
+    // (profiles/r2g_vit_knobs.txt) 128-row tiles with 32-deep steps at three blocks per CU beat the 256 x 256 tile (the GELU
+    // epilogue has nothing to hide behind at one block per CU) and the 64-deep steps (594 tiles do not fill 2 x 256 slots twice)
+    const bool vit = h && h->vit;
+    const bool big = !vit && conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
-    const int BK = big ? 64 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr);
+    const int BK = big ? 64 : (vit ? 32 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr));
     const int BM = big ? 256 : conv_bm(d.kh, d.kw, M);
     // measured: issuing the DMA after the first MFMA group gains ~7 % on the 256x256 3x3 launches and
     // loses 3-5 % on the 128-row tiles and on every 1x1
@@ -735,7 +739,12 @@ const char* launch_layernorm(fav_handle* h, const void* x, long long ldx, const 
 const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, int T, int D, int heads, int math_mode, hipStream_t s) {
     if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
     const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
-    const int lds = nkt * 16 * 128 + 64 * vstride + 8 * 16 * vstride;
+    // one wave per query tile if their P strips fit beside K and V^T (197 tokens: 13 waves, 153 KB), else 8 waves round robin
+    int nw = nkt > 8 ? nkt : 8;
+    if (nkt * 16 * 128 + 64 * vstride + nw * 16 * vstride > 160 * 1024) nw = 8;
+    static const int attn_nw = [] { const char* e = getenv("FAV_ATTN_WAVES"); return e ? atoi(e) : 0; }();   // experiments: 8 forces the old shape
+    if (attn_nw == 8) nw = 8;
+    const int lds = nkt * 16 * 128 + 64 * vstride + nw * 16 * vstride;
     static DeviceFlags attr_set;
     if (!attr_set.test_current()) {
         if (hipFuncSetAttribute((const void*)attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -746,9 +755,9 @@ const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, i
     const double flops = 4.0 * n * heads * (double)T * T * 64;
     Prof pr(h, s, FAV_K_CONV, flops, (double)n * T * D * 2 * 4);
     if (math_mode == FAV_MATH_BF16)
-        hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)(n * heads)), dim3(512), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+        hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)(n * heads)), dim3(nw * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
     else
-        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)(n * heads)), dim3(512), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)(n * heads)), dim3(nw * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
     return nullptr;
 }
 

@@ -2032,29 +2032,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 //   row max / sum by the lane (sequential over its keys) and two xor-shuffles, e = fav_expf(s - max),
 //   p = e * (1 / sum) rounded to bf16 through a per-wave LDS strip, O = V^T P^T on MFMA over keys ascending.
 // The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate.
+// The block has one wave per query tile when the P strips of that many waves fit in LDS (197 tokens: 13 waves, one
+// pass, every wave busy), else 8 waves that take the tiles round robin.
 template <int MODE>
-__global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
-                                                        int heads) {
+__global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
+                                                         int heads) {
     extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
     const int nkt = (T + 15) >> 4;             // key tiles of 16
     const int Tp2 = ((T + 31) >> 5) << 5;      // keys padded for the 32-deep second product
     const int vstride = Tp2 * 2 + 16;          // bytes per V^T / P row (the +16 spreads rows over the banks)
     unsigned char* const Ks = asm_;                                   // [nkt*16][128 B], chunk ^= row & 7
     unsigned char* const Vt = Ks + nkt * 16 * 128;                    // [64][vstride]
-    unsigned char* const Ps = Vt + 64 * vstride;                      // [8 waves][16][vstride]
+    unsigned char* const Ps = Vt + 64 * vstride;                      // [waves][16][vstride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nwaves = nthr >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int h = blockIdx.x % heads;
     const long long f = blockIdx.x / heads;
     const uint16_t* base = qkv + f * (long long)T * 3 * D;
     // ---- stage K and V^T (zero beyond T) ----
-    for (int i = tid; i < nkt * 16 * 8; i += 512) {
+    for (int i = tid; i < nkt * 16 * 8; i += nthr) {
         const int row = i >> 3, ch = i & 7;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < T) v = *(const uint4*)(base + (long long)row * 3 * D + D + h * 64 + ch * 8);
         *(uint4*)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
     }
-    for (int i = tid; i < Tp2 * 8; i += 512) {
+    for (int i = tid; i < Tp2 * 8; i += nthr) {
         const int key = i >> 3, ch = i & 7;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (key < T) v = *(const uint4*)(base + (long long)key * 3 * D + 2 * D + h * 64 + ch * 8);
@@ -2070,7 +2073,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
     __syncthreads();
 
     const int nqt = (T + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 8) {
+    for (int qt = wave; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + frow;          // this lane's query (as MFMA column)
         uint4 fqv[2];
 #pragma unroll
