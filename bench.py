@@ -313,7 +313,7 @@ def main():
             total_ms = sum(v["ms"] for v in prof.values())
             tf = cv["flops"] / secs / 1e12 if secs > 0 else 0.0
             gbs = cv["bytes"] / secs / 1e9 if secs > 0 else 0.0
-            common = {"kernel": "fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel "
+            common = {"kernel": "fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel + fav::entry_reduce_kernel "
                                 "(every conv / fc launch of the timed steps)",
                       "launches": cv["launches"], "avg_launch_us": 1e3 * cv["ms"] / max(1, cv["launches"]),
                       "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None,
