@@ -439,7 +439,9 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     } while (0)
 #define FAV_LAUNCH_BIG(MODE_)                                                                                     \
     do {                                                                                                          \
-        if (epi) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 1>), grid, dim3(512), 0, s, p);    \
+        static const int pp = [] { const char* e = getenv("FAV_CONV_PP"); return e ? atoi(e) : 1; }();           \
+        if (epi && pp && MODE_ == 0) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0, 2, 0, 1, 1>), grid, dim3(512), 0, s, p); \
+        else if (epi) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 1>), grid, dim3(512), 0, s, p);    \
         else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 0>), grid, dim3(512), 0, s, p);        \
     } while (0)
     if (big) {

@@ -309,7 +309,7 @@ constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
 // GELU, Philox dropout (one call = exactly its 16 draws) and the bf16 rounding need no fp32 staging through LDS and no
 // barrier.  (Tiles with 32 columns per wave use 32-row groups and 8 channels per lane.)  The sums are unchanged - an
 // output element still meets its products in ascending k.  EPI = 0 is the round-1 epilogue through an fp32 LDS stage.
-template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1>
+template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1, int PP = 0>
 __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = (BM / 64) * WN * 64;     // threads: (BM/64) x WN waves, each a 64 x BN/WN sub-tile
     constexpr int NWAVES = NT / 64;
@@ -537,6 +537,81 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 1] = wall_clock64();
 
     int cur = 0, nxt = NS - 1;  // stage being read / stage being filled
+    if constexpr (PP == 1) {
+        // ---- ping-pong K loop (256 x 256 x 64 tile, 8 waves, two stages) ---------------------------------------------
+        // Waves w and w + 4 share a SIMD.  Re-aligned by the per-step barrier they would both read fragments, then both
+        // multiply: LDS and the matrix pipe take turns.  Here waves 4..7 run half a step behind - they carry the fragments
+        // of a tile's second 32-deep half across the barrier and multiply them while waves 0..3 read - so one wave of a
+        // SIMD feeds the matrix pipe while the other one reads.  Every accumulator still meets its products in ascending k.
+        static_assert(BK == 64 && NS == 2 && MODE == 0 && NT == 512, "ping-pong loop: 8 waves, 64-deep steps, two stages");
+#define FAV_PP_READ(FX, FW, KK)                                                                          \
+    do {                                                                                                \
+        _Pragma("unroll") for (int b = 0; b < TM; ++b) {                                                \
+            const int row = wm * WTM + b * 16 + frow;                                                   \
+            FX[b] = *(const uint4*)(As + row * ROWB + ((((KK) * 4 + fq) ^ lds_swz<BK>(row)) << 4));     \
+        }                                                                                               \
+        _Pragma("unroll") for (int a = 0; a < TN; ++a) {                                                \
+            const int row = wn * WTN + a * 16 + frow;                                                   \
+            FW[a] = *(const uint4*)(Bs + row * ROWB + ((((KK) * 4 + fq) ^ lds_swz<BK>(row)) << 4));     \
+        }                                                                                               \
+    } while (0)
+#define FAV_PP_MMA(FX, FW)                                                                               \
+    do {                                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                  \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b) {                                            \
+                union { uint4 u; bf16x8_t v; } ua, ub;                                                  \
+                ua.u = FW[a]; ub.u = FX[b];                                                             \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[a][b], 0, 0, 0);    \
+            }                                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+    } while (0)
+#define FAV_PP_STEP_END()                                                                                \
+    do {                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        __syncthreads();                                                                                \
+        cur ^= 1; nxt ^= 1;                                                                             \
+    } while (0)
+        if (wave_u < NWAVES / 2) {
+            for (int kt = 0; kt < p.nk; ++kt) {
+                const unsigned char* As = smem + cur * STAGE_BYTES;
+                const unsigned char* Bs = As + A_BYTES;
+                uint4 fx[TM], fw[TN];
+                FAV_PP_READ(fx, fw, 0);
+                if (kt + 1 < p.nk) FAV_STAGE(nxt, kt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_MMA(fx, fw);
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_READ(fx, fw, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_MMA(fx, fw);
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_STEP_END();
+            }
+        } else {
+            uint4 hx[TM], hw[TN];        // second half of the previous tile, carried across the barrier
+            for (int kt = 0; kt < p.nk; ++kt) {
+                const unsigned char* As = smem + cur * STAGE_BYTES;
+                const unsigned char* Bs = As + A_BYTES;
+                if (kt > 0) FAV_PP_MMA(hx, hw);
+                if (kt + 1 < p.nk) FAV_STAGE(nxt, kt + 1);      // (issuing the DMA first in the step measured 3-6 % slower)
+                __builtin_amdgcn_sched_barrier(0);
+                uint4 fx[TM], fw[TN];
+                FAV_PP_READ(fx, fw, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_MMA(fx, fw);
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_READ(hx, hw, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // in registers before the stage may be overwritten
+                __builtin_amdgcn_sched_barrier(0);
+                FAV_PP_STEP_END();
+            }
+            if (p.nk > 0) FAV_PP_MMA(hx, hw);
+        }
+#undef FAV_PP_READ
+#undef FAV_PP_MMA
+#undef FAV_PP_STEP_END
+    } else
     for (int kt = 0; kt < p.nk; ++kt) {
         if ((BK == 32 || !p.stage_mid) && kt + NS - 1 < p.nk) FAV_STAGE(nxt, kt + NS - 1);
         const unsigned char* As = smem + cur * STAGE_BYTES;
