@@ -129,6 +129,8 @@ struct fav_handle {
                       hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     std::vector<MemberWs> mws;
     hipEvent_t ev_members = nullptr;
+    std::vector<hipStream_t> vit_streams;   // ViT: parts of the batch side by side
+    std::vector<hipEvent_t> vit_done;
     bool plan_no_fuse = false;      // fav_plan_schedule: build the layer-by-layer schedule (the fused one's reference)
     std::vector<void*> phase_out;   // output tensor of each phase
     float* logits = nullptr;        // [T][max_batch][cpad]
@@ -1270,6 +1272,8 @@ void free_all(fav_handle* h) {
         if (w.done) (void)hipEventDestroy(w.done);
     }
     if (h->ev_members) (void)hipEventDestroy(h->ev_members);
+    for (auto st_ : h->vit_streams) (void)hipStreamDestroy(st_);
+    for (auto ev_ : h->vit_done) (void)hipEventDestroy(ev_);
     for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
     if (h->logits) (void)hipFree(h->logits);
     if (h->host_stage) (void)hipFree(h->host_stage);
@@ -1324,11 +1328,24 @@ fav_status build_vit(fav_handle* h) {
 }
 
 // One forward pass of the ViT encoder over n frames -> fp32 logits [n][cpad].
-fav_status run_vit(fav_handle* h, const void* images, int layout, int n, hipStream_t s) {
+// Frames [f0, f0 + n) of the call: every buffer is indexed by frame, so two halves of a batch can run side by side
+// on two streams (fav_classify_ex).
+fav_status run_vit(fav_handle* h, const void* images_all, int layout, int f0, int n, hipStream_t s) {
     const fav_config& c = h->cfg;
     const VitDef& V = kVit[c.arch - 2];
     const int ntok = h->vit_ntok, D = V.dim, gh = c.in_h / V.patch, gw = c.in_w / V.patch;
     const float inv_std[3] = {1.0f / c.stdev[0], 1.0f / c.stdev[1], 1.0f / c.stdev[2]};
+    const size_t F = (size_t)f0, np = (size_t)gh * gw;
+    const void* images = (const char*)images_all + F * c.in_h * c.in_w * 3 * (layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4);
+    struct { void *v_patches, *v_emb, *v_x, *v_y, *v_qkv, *v_hid, *v_cls; float* logits; } B;
+    B.v_patches = (char*)h->v_patches + F * np * (size_t)(V.patch * V.patch * 3) * 2;
+    B.v_emb = (char*)h->v_emb + F * np * D * 2;
+    B.v_x = (char*)h->v_x + F * ntok * D * 2;
+    B.v_y = (char*)h->v_y + F * ntok * D * 2;
+    B.v_qkv = (char*)h->v_qkv + F * ntok * 3 * D * 2;
+    B.v_hid = (char*)h->v_hid + F * ntok * (size_t)V.mlp * 2;
+    B.v_cls = (char*)h->v_cls + F * D * 2;
+    B.logits = h->logits + F * h->cpad;
     auto gemm = [&](int layer, const void* x, int rows_per_frame, const void* res, int act, void* y, int out_f32) -> const char* {
         const Layer& L = h->layers[layer];
         fav_conv_desc d;
@@ -1345,23 +1362,23 @@ fav_status run_vit(fav_handle* h, const void* images, int layout, int n, hipStre
     } while (0)
     h->cur_op = -1;
     // patch embedding: normalise + im2col (k = (r*P + s)*3 + c), GEMM, add positions / class token
-    launch_stem(h, images, layout, n, c.in_h, c.in_w, V.patch, V.patch, V.patch, 0, V.patch * V.patch * 3, c.mean, inv_std, h->v_patches, s);
-    FAV_VIT_TRY(gemm(0, h->v_patches, gh * gw, nullptr, 0, h->v_emb, 0));
-    launch_vit_assemble(h, h->v_emb, (const float*)h->layers[1].w, h->v_x, n, ntok, D, s);
+    launch_stem(h, images, layout, n, c.in_h, c.in_w, V.patch, V.patch, V.patch, 0, V.patch * V.patch * 3, c.mean, inv_std, B.v_patches, s);
+    FAV_VIT_TRY(gemm(0, B.v_patches, gh * gw, nullptr, 0, B.v_emb, 0));
+    launch_vit_assemble(h, B.v_emb, (const float*)h->layers[1].w, B.v_x, n, ntok, D, s);
     int li = 2;
     for (int blk = 0; blk < V.depth; ++blk, li += 6) {
         const Layer &ln1 = h->layers[li], &ln2 = h->layers[li + 3];
-        FAV_VIT_TRY(launch_layernorm(h, h->v_x, D, (const float*)ln1.w, ln1.b, h->v_y, (long long)n * ntok, D, 1e-6f, s));
-        FAV_VIT_TRY(gemm(li + 1, h->v_y, ntok, nullptr, 0, h->v_qkv, 0));
-        FAV_VIT_TRY(launch_attention(h, h->v_qkv, h->v_y, n, ntok, D, V.heads, c.math_mode, s));
-        FAV_VIT_TRY(gemm(li + 2, h->v_y, ntok, h->v_x, 0, h->v_x, 0));                 // x = x + proj(attn), in place tile by tile
-        FAV_VIT_TRY(launch_layernorm(h, h->v_x, D, (const float*)ln2.w, ln2.b, h->v_y, (long long)n * ntok, D, 1e-6f, s));
-        FAV_VIT_TRY(gemm(li + 4, h->v_y, ntok, nullptr, 2, h->v_hid, 0));              // GELU fused
-        FAV_VIT_TRY(gemm(li + 5, h->v_hid, ntok, h->v_x, 0, h->v_x, 0));
+        FAV_VIT_TRY(launch_layernorm(h, B.v_x, D, (const float*)ln1.w, ln1.b, B.v_y, (long long)n * ntok, D, 1e-6f, s));
+        FAV_VIT_TRY(gemm(li + 1, B.v_y, ntok, nullptr, 0, B.v_qkv, 0));
+        FAV_VIT_TRY(launch_attention(h, B.v_qkv, B.v_y, n, ntok, D, V.heads, c.math_mode, s));
+        FAV_VIT_TRY(gemm(li + 2, B.v_y, ntok, B.v_x, 0, B.v_x, 0));                 // x = x + proj(attn), in place tile by tile
+        FAV_VIT_TRY(launch_layernorm(h, B.v_x, D, (const float*)ln2.w, ln2.b, B.v_y, (long long)n * ntok, D, 1e-6f, s));
+        FAV_VIT_TRY(gemm(li + 4, B.v_y, ntok, nullptr, 2, B.v_hid, 0));              // GELU fused
+        FAV_VIT_TRY(gemm(li + 5, B.v_hid, ntok, B.v_x, 0, B.v_x, 0));
     }
     const Layer& lnf = h->layers[li];
-    FAV_VIT_TRY(launch_layernorm(h, h->v_x, (long long)ntok * D, (const float*)lnf.w, lnf.b, h->v_cls, n, D, 1e-6f, s));   // class tokens only
-    FAV_VIT_TRY(gemm(li + 1, h->v_cls, 1, nullptr, 0, h->logits, 1));
+    FAV_VIT_TRY(launch_layernorm(h, B.v_x, (long long)ntok * D, (const float*)lnf.w, lnf.b, B.v_cls, n, D, 1e-6f, s));   // class tokens only
+    FAV_VIT_TRY(gemm(li + 1, B.v_cls, 1, nullptr, 0, B.logits, 1));
 #undef FAV_VIT_TRY
     return FAV_OK;
 }
@@ -1587,8 +1604,31 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     h->ev_used = h->profiling ? h->ev_used : 0;
     if (h->vit) {
         for (auto& L : h->layers) { L.w = L.w_m[0]; L.b = L.b_m[0]; }
-        fav_status st = run_vit(h, images, layout, n, s);
-        if (st != FAV_OK) return st;
+        // the batch in FAV_VIT_STREAMS (default 2) parts on as many streams: at 197 rows per frame every GEMM of the encoder is a
+        // few hundred tiles, and the partial last round of one part's launch is filled by another part's (1: one stream)
+        static const int vit_streams = [] { const char* e = getenv("FAV_VIT_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+        if (vit_streams > 1 && n >= 8 * vit_streams && !h->profiling) {
+            if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            while ((int)h->vit_streams.size() < vit_streams) {
+                hipStream_t st_; hipEvent_t ev_;
+                HIP_TRY(h, hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+                h->vit_streams.push_back(st_); h->vit_done.push_back(ev_);
+            }
+            HIP_TRY(h, hipEventRecord(h->ev_fork, s));
+            fav_status st = FAV_OK;
+            for (int part = 0; part < vit_streams && st == FAV_OK; ++part) {
+                const int f0 = (int)((long long)n * part / vit_streams), f1 = (int)((long long)n * (part + 1) / vit_streams);
+                HIP_TRY(h, hipStreamWaitEvent(h->vit_streams[part], h->ev_fork, 0));
+                st = run_vit(h, images, layout, f0, f1 - f0, h->vit_streams[part]);
+                HIP_TRY(h, hipEventRecord(h->vit_done[part], h->vit_streams[part]));
+                HIP_TRY(h, hipStreamWaitEvent(s, h->vit_done[part], 0));
+            }
+            if (st != FAV_OK) return st;
+        } else {
+            fav_status st = run_vit(h, images, layout, 0, n, s);
+            if (st != FAV_OK) return st;
+        }
     } else if (!h->mws.empty()) {
         // members side by side: fork from the caller's stream, one stream per member, join before the head
         HIP_TRY(h, hipEventRecord(h->ev_members, s));
