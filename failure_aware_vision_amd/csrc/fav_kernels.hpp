@@ -1252,11 +1252,45 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull] = wall_clock64();
 
-    // ---- P0: biases (plain loads, issued before any DMA), descriptors, the first requests -----------------
-    if (HAS3X3) for (int i = tid; i < CMID; i += NT) bias_b_s[(i >> 4) * 20 + (i & 15)] = p.bias_b[i];
-    for (int i = tid; i < COUT; i += NT) bias_c_s[(i >> 4) * 20 + (i & 15)] = p.bias_c[i];
-    if (NRED > 0) for (int i = tid; i < NRED; i += NT) bias_a_s[(i >> 4) * 20 + (i & 15)] = p.bias_a[i];
+    // ---- P0: biases, descriptors, the first requests ----------------------------------------------------------------
+    // The bias values are REQUESTED here, all at once, and written to LDS only after the first LDS-DMA requests are out:
+    // written where they are loaded, each `global_load` waited for its own data before the next one - and before the
+    // patch - was even requested (three L2 round trips, ~2 us, in front of every tile).
+    constexpr int NBB = HAS3X3 ? (CMID + NT - 1) / NT : 0, NBC = (COUT + NT - 1) / NT, NBA = NRED > 0 ? (NRED + NT - 1) / NT : 0;
+    float bias_v[NBB + NBC + NBA];
+#pragma unroll
+    for (int k = 0; k < NBB; ++k) bias_v[k] = (tid + k * NT < CMID) ? p.bias_b[tid + k * NT] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NBC; ++k) bias_v[NBB + k] = (tid + k * NT < COUT) ? p.bias_c[tid + k * NT] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NBA; ++k) bias_v[NBB + NBC + k] = (tid + k * NT < NRED) ? p.bias_a[tid + k * NT] : 0.f;
+#define FAV_T_BIAS_TO_LDS()                                                                                       \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < NBB; ++k) {                                                         \
+            const int i = tid + k * NT;                                                                           \
+            if (i < CMID) bias_b_s[(i >> 4) * 20 + (i & 15)] = bias_v[k];                                         \
+        }                                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < NBC; ++k) {                                                         \
+            const int i = tid + k * NT;                                                                           \
+            if (i < COUT) bias_c_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + k];                                   \
+        }                                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < NBA; ++k) {                                                         \
+            const int i = tid + k * NT;                                                                           \
+            if (i < NRED) bias_a_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + NBC + k];                             \
+        }                                                                                                         \
+    } while (0)
     if (tid < 4) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
+    // the residual of chunk 0 comes from HBM: requested now, it lands under conv_b instead of in front of P2's first epilogue
+    const __amdgpu_buffer_rsrc_t srd_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((HAS_RES ? p.res : p.y) + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
+    u32x4_t rnext[TM2][2];
+#define FAV_T_LOAD_RES(J)                                                                                        \
+    if (HAS_RES) _Pragma("unroll") for (int b = 0; b < TM2; ++b) {                                               \
+        const int off = ((wave * RP + b * 16 + frow) * COUT + (J) * 64 + fq * 16) * 2;                           \
+        rnext[b][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off, 0, 0);                                 \
+        rnext[b][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off + 16, 0, 0);                            \
+    }
+    FAV_T_LOAD_RES(0)
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)tsm);
     const uint32_t lds_regb = lds_base + (P1G ? 0u : (uint32_t)p.rega_bytes);
@@ -1339,6 +1373,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         }                                                                                                        \
     } while (0)
             FAV_T_GSTAGE(0, 0);
+            FAV_T_BIAS_TO_LDS();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
@@ -1424,6 +1459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             }
             tapmask[b] = mk;
         }
+        FAV_T_BIAS_TO_LDS();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
         __syncthreads();
         if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
@@ -1537,6 +1573,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 t2f[b][ks] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
+        FAV_T_BIAS_TO_LDS();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights (and the fragments)
         __syncthreads();
     }
@@ -1544,18 +1581,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 
     // ---- P2 ---------------------------------------------------------------------------------------------------
     // lane (frow, fq) finishes channels 64j + 16fq .. + 15 of pixel rows wave*RP + b*16 + frow
-    const __amdgpu_buffer_rsrc_t srd_res =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_y =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
-    u32x4_t rnext[TM2][2], rcur[TM2][2];
-#define FAV_T_LOAD_RES(J)                                                                                        \
-    if (HAS_RES) _Pragma("unroll") for (int b = 0; b < TM2; ++b) {                                               \
-        const int off = ((wave * RP + b * 16 + frow) * COUT + (J) * 64 + fq * 16) * 2;                           \
-        rnext[b][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off, 0, 0);                                 \
-        rnext[b][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off + 16, 0, 0);                            \
-    }
-    FAV_T_LOAD_RES(0)
+    u32x4_t rcur[TM2][2];
     uint32_t drop_v[TM2], drop_pix[TM2];
 #pragma unroll
     for (int b = 0; b < TM2; ++b) {
@@ -1711,6 +1739,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 #undef FAV_T_LOAD_RES
 #undef FAV_T_STAGE_WC
 #undef FAV_T_STAGE_WA
+#undef FAV_T_BIAS_TO_LDS
 
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 4] = wall_clock64();
     // ---- P3: t1' = bf16(relu(acc3 + bias_a)): lane holds channels 64*g3 + 16fq .. + 15 of its pixel rows ----------
