@@ -463,9 +463,11 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + (wave * AR + i) * PROWS + lrow;
         if (m < p.M) {
-            const int vimg = m / p.HWo;
+            // magic-number divisions (two per staged row; as plain `/` they were ~300 of the ~440 instructions in front of
+            // the first LDS-DMA request)
+            const int vimg = (int)fastdiv((uint32_t)m, p.div_hwo);
             const int pix = m - vimg * p.HWo;
-            const int oh = pix / p.Wo, ow = pix - oh * p.Wo;
+            const int oh = (int)fastdiv((uint32_t)pix, p.div_w), ow = pix - oh * p.Wo;
             a_ih0[i] = oh * p.stride - p.pad;
             a_iw0[i] = ow * p.stride - p.pad;
             a_voff[i] = (uint32_t)(((long long)(vimg - vimg0) * frame_elems +
