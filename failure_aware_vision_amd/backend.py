@@ -8,9 +8,10 @@ Mirrors the reference's scorer interface so it plugs into the same seam:
   the shape of SignalAnalyzer.analyze_frame, platform/backend/signal_analyzer.py:47-143,
   whose result is fed to ``TrustEngine.update(vision_status, anomaly_score, dt)``
   (main.py:160-168);
-* errors are reported the reference's way at the seam: ``analyze_frame`` returns
-  ``anomaly_score=None`` on failure, which the engine tolerates
-  (trust_engine.py:101-103,193); ``classify`` itself raises.
+* errors at the seam: a malformed frame raises (a caller bug); a failure of the GPU
+  path is reported as a NON-OK ``vision_status`` with a numeric ``anomaly_score``
+  (main.py:169 rounds the score, and an unseen frame must not count as healthy:
+  trust_engine.py:179-190); ``classify`` itself raises.
 
 All arithmetic happens in the HIP library behind include/fav.h.  torch is used
 only for device buffers and the current stream.
@@ -186,22 +187,39 @@ class Backend:
         return [{f: getattr(r, f) for f, _ in _lib.FavOpProfile._fields_ if f != "reserved"} for r in arr]
 
     # -- the reference seam ----------------------------------------------------------
+    #: what the seam reports when the GPU path itself fails (never 'VISION_OK': the trust engine must not recover
+    #: reliability on a frame nobody looked at, trust_engine.py:179-190)
+    FAILED_STATUS = "VISION_CORRUPTED"
+
     def analyze_frame(self, frame: np.ndarray, status_provider=None) -> dict:
         """ONE call at the seam (main.py:160): a uint8 HxWx3 frame -> the dict SignalAnalyzer.analyze_frame returns
-        (signal_analyzer.py:128-143), carrying BOTH the rule-based ``vision_status`` of the reference's scorer and
-        the classifier-derived ``anomaly_score`` in [0,1] (rounded to 6 places), ready for
-        ``TrustEngine.update(vision_status, anomaly_score, dt)`` (main.py:168).
+        (signal_analyzer.py:128-143), with the SAME keys the caller reads (main.py:163-177: ``anomaly_score``,
+        ``vision_status``, ``metrics['blur']``, ``metrics['brightness']``, ...).  ``vision_status`` and the
+        ``metrics`` entries of the reference are the rule scorer's (computed on the GPU by the fused
+        signal-statistics kernel, signal.py); ``anomaly_score`` is the classifier's clamp(1 - confidence), rounded
+        to 6 places, always a number (main.py:169 rounds it); ``metrics['classifier']`` = {label, confidence, fail,
+        samples} and ``metrics['rule_anomaly_score']`` carry the rest.
 
-        The frame is uploaded once; the fused signal-statistics kernel (signal.py, the reference's four pixel
-        metrics) and the classifier are queued on the same stream and the host synchronises once.  The
-        classifier is an ML sensor only (ML influence is active only under VISION_OK, trust_engine.py:179,192);
-        the rule metrics stay available under ``metrics['signal']``.  ``status_provider(frame) -> str`` replaces the
-        built-in rules when given.  On failure ``anomaly_score`` is None, which the engine tolerates
-        (trust_engine.py:101-103,193)."""
+        The frame is uploaded once; both kernels are queued on one stream and the host synchronises once.
+        ``status_provider(frame) -> str`` replaces the built-in rules (the reference's metric keys are then 0.0).
+
+        Errors.  A frame of the wrong type, dtype or shape is a caller bug: TypeError / ValueError, as
+        ``classify`` raises.  A failure of the GPU path (FavError, a HIP error surfacing through torch) does NOT
+        read as a healthy frame: the result is ``vision_status = FAILED_STATUS``, ``anomaly_score = 1.0`` and
+        ``metrics['error']`` - the engine then decays trust at its corrupted-frame rate (trust_engine.py:218-224) -
+        and the rule scorer's previous-frame state is left as it was before the call."""
         torch = self._torch
-        status, rule_metrics = "VISION_OK", None
+        if not isinstance(frame, np.ndarray):
+            raise TypeError(f"analyze_frame takes a numpy uint8 HxWx3 frame (video_source.py:144-148), got {type(frame).__name__}")
+        if frame.dtype != np.uint8:
+            raise TypeError(f"analyze_frame takes uint8 pixels, got {frame.dtype}")
+        if frame.shape != (self.cfg.in_h, self.cfg.in_w, 3):
+            raise ValueError(f"expected a frame of shape ({self.cfg.in_h}, {self.cfg.in_w}, 3), got {tuple(frame.shape)}")
+        fr = np.ascontiguousarray(frame)
+        ref_metrics = {"blur": 0.0, "brightness": 0.0, "freeze": 0.0, "entropy": 0.0, "raw": {}}
+        rule_score = None
+        rules, saved = None, None
         try:
-            fr = np.ascontiguousarray(frame)
             if status_provider is not None:
                 status = status_provider(frame)
                 labels, conf, fail, score = self.classify_detect(fr[None])
@@ -210,21 +228,26 @@ class Backend:
                 if self._rules is None:
                     from .signal import SignalAnalyzerHIP
                     self._rules = SignalAnalyzerHIP(self.device)
+                rules, saved = self._rules, self._rules.save_state()
                 dev = torch.from_numpy(fr[None]).to(f"cuda:{self.device}")
-                stats_dev = self._rules.launch_stats(dev)
+                stats_dev = rules.launch_stats(dev)
                 labels, conf, fail, score = self.classify_detect(dev)
                 packed = torch.stack([labels.to(torch.float32), conf, fail.to(torch.float32), score])   # [4, 1]
                 host = torch.cat([stats_dev, packed.view(torch.uint8).flatten()]).cpu().numpy()          # the one sync
                 nstat = stats_dev.numel()
-                rule = self._rules.score_stats(self._rules.parse_stats(host[:nstat].tobytes(), 1))[0]
-                status, rule_metrics = rule["vision_status"], rule
+                rule = rules.score_stats(rules.parse_stats(host[:nstat].tobytes(), 1))[0]
+                status, ref_metrics, rule_score = rule["vision_status"], dict(rule["metrics"]), rule["anomaly_score"]
                 vals = host[nstat:].view(np.float32)
                 l0, c0, f0, s0 = int(vals[0]), float(vals[1]), bool(vals[2]), float(vals[3])
-        except Exception:  # the seam's convention: no ML score available (trust_engine.py:101-103)
-            return {"anomaly_score": None, "vision_status": status, "metrics": {}}
-        metrics = {"label": l0, "confidence": round(c0, 4), "fail": f0, "samples": self.T}
-        if rule_metrics is not None:
-            metrics["signal"] = dict(rule_metrics["metrics"], anomaly_score=rule_metrics["anomaly_score"])
+        except (_lib.FavError, RuntimeError) as e:       # the device path failed: fail closed (see the docstring)
+            if rules is not None:
+                rules.restore_state(saved)
+            return {"anomaly_score": 1.0, "vision_status": self.FAILED_STATUS,
+                    "metrics": dict(ref_metrics, error=f"{type(e).__name__}: {e}")}
+        metrics = dict(ref_metrics)
+        metrics["classifier"] = {"label": l0, "confidence": round(c0, 4), "fail": f0, "samples": self.T}
+        if rule_score is not None:
+            metrics["rule_anomaly_score"] = rule_score
         return {"anomaly_score": round(s0, 6), "vision_status": status, "metrics": metrics}
 
 

@@ -36,6 +36,16 @@ std::string fmt(const char* f, ...) {
     return buf;
 }
 
+// inside a fork/join region: remember the first failure but keep going, so that every forked stream is joined
+#define HIP_KEEP(h, st, expr)                                                                    \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess && (st) == FAV_OK) {                                                \
+            (h)->err = fmt("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (st) = FAV_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
 #define HIP_TRY(h, expr)                                                                         \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
@@ -140,6 +150,11 @@ struct fav_handle {
     int first_site = -1;
     void* host_stage = nullptr;     // for fav_classify_host
     hipStream_t host_stream = nullptr;
+    // Every call that touches the handle's buffers (act[], a1, phase outputs, logits) records ev_last on its stream when it has
+    // queued its work, and the next call makes ITS stream wait for that event first: two calls on different streams (a torch
+    // stream and host_stream, or two torch streams) are then ordered on the device instead of racing on the activations.
+    hipEvent_t ev_last = nullptr;
+    bool ev_last_set = false;
     // ViT path (arch 2, 3): layers in blob order (kh == 0: a pair of fp32 vectors kept in w / b), fixed buffers
     bool vit = false;
     int vit_ntok = 0;
@@ -309,6 +324,10 @@ bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
 const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int ldy, hipStream_t s) {
     if (d.Cin % 64 != 0) return "conv: Cin must be a multiple of 64";
     if (cout_pad % 64 != 0) return "conv: padded Cout must be a multiple of 64";
+    // the bf16 epilogues store whole 16-byte groups of channels and range-check rows only: padded columns would land in
+    // the next pixel's first channels.  Only the fp32 (logit) output, whose row pitch is the padded width, may be padded.
+    if (!d.out_f32 && cout_pad != d.Cout) return "conv: a bf16 output needs Cout to be a multiple of 64 (no column padding)";
+    if (d.out_f32 && ldy < cout_pad) return "conv: the fp32 output's row pitch must cover the padded Cout";
     if (cout_pad == d.Cout && ldy == d.Cout && launch_proj(h, d, s)) return nullptr;
     ConvParams p;
     p.x = (const uint16_t*)d.x; p.w = (const uint16_t*)d.w; p.bias = d.bias; p.res = (const uint16_t*)d.res; p.y = d.y;
@@ -1278,6 +1297,7 @@ void free_all(fav_handle* h) {
     if (h->logits) (void)hipFree(h->logits);
     if (h->host_stage) (void)hipFree(h->host_stage);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     for (void* q : {h->v_patches, h->v_emb, h->v_x, h->v_y, h->v_qkv, h->v_hid, h->v_cls}) if (q) (void)hipFree(q);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 }
@@ -1591,6 +1611,20 @@ fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* bl
     return FAV_OK;
 }
 
+namespace {
+// orders this call's stream behind the previous user of the handle's buffers (see fav_handle::ev_last)
+fav_status wait_last_use(fav_handle* h, hipStream_t s) {
+    if (!h->ev_last) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
+    if (h->ev_last_set) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_last, 0));
+    return FAV_OK;
+}
+void mark_last_use(fav_handle* h, hipStream_t s) {
+    if (h->ev_last && hipEventRecord(h->ev_last, s) == hipSuccess) h->ev_last_set = true;
+}
+fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
+                              int32_t* labels, float* conf, uint8_t* fail, float* score, hipStream_t s);
+}  // namespace
+
 fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
                            int32_t* labels, float* conf, uint8_t* fail, float* score, void* stream) {
     if (!h) return FAV_ERR_INVALID_ARG;
@@ -1601,6 +1635,15 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     if (first_index < 0 || first_index + n > 0xFFFFFFFFll) { h->err = "fav_classify: first_image_index out of range"; return FAV_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (fav_status st = wait_last_use(h, s)) return st;
+    const fav_status st = classify_on_stream(h, images, n, layout, first_index, labels, conf, fail, score, s);
+    mark_last_use(h, s);      // also after a failure: whatever was queued before it still uses the buffers
+    return st;
+}
+
+namespace {
+fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
+                              int32_t* labels, float* conf, uint8_t* fail, float* score, hipStream_t s) {
     h->ev_used = h->profiling ? h->ev_used : 0;
     if (h->vit) {
         for (auto& L : h->layers) { L.w = L.w_m[0]; L.b = L.b_m[0]; }
@@ -1616,13 +1659,13 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
                 h->vit_streams.push_back(st_); h->vit_done.push_back(ev_);
             }
             HIP_TRY(h, hipEventRecord(h->ev_fork, s));
-            fav_status st = FAV_OK;
-            for (int part = 0; part < vit_streams && st == FAV_OK; ++part) {
+            fav_status st = FAV_OK;     // from here to the join nothing returns: a forked stream is always joined into s
+            for (int part = 0; part < vit_streams; ++part) {
                 const int f0 = (int)((long long)n * part / vit_streams), f1 = (int)((long long)n * (part + 1) / vit_streams);
-                HIP_TRY(h, hipStreamWaitEvent(h->vit_streams[part], h->ev_fork, 0));
-                st = run_vit(h, images, layout, f0, f1 - f0, h->vit_streams[part]);
-                HIP_TRY(h, hipEventRecord(h->vit_done[part], h->vit_streams[part]));
-                HIP_TRY(h, hipStreamWaitEvent(s, h->vit_done[part], 0));
+                HIP_KEEP(h, st, hipStreamWaitEvent(h->vit_streams[part], h->ev_fork, 0));
+                if (st == FAV_OK) st = run_vit(h, images, layout, f0, f1 - f0, h->vit_streams[part]);
+                HIP_KEEP(h, st, hipEventRecord(h->vit_done[part], h->vit_streams[part]));
+                HIP_KEEP(h, st, hipStreamWaitEvent(s, h->vit_done[part], 0));
             }
             if (st != FAV_OK) return st;
         } else {
@@ -1632,19 +1675,20 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     } else if (!h->mws.empty()) {
         // members side by side: fork from the caller's stream, one stream per member, join before the head
         HIP_TRY(h, hipEventRecord(h->ev_members, s));
+        fav_status st = FAV_OK;         // nothing returns between the fork and the join
         for (int member = 0; member < h->n_members; ++member) {
             fav_handle::MemberWs& w = h->mws[member];
             for (auto& L : h->layers) { L.w = L.w_m[member]; L.b = L.b_m[member]; }   // read when the launches are enqueued
             w.phase_out.back() = (char*)h->logits + (size_t)member * n * h->cpad * 4;
-            HIP_TRY(h, hipStreamWaitEvent(w.stream, h->ev_members, 0));
-            for (size_t pi = 0; pi < h->phases.size(); ++pi) {
+            HIP_KEEP(h, st, hipStreamWaitEvent(w.stream, h->ev_members, 0));
+            for (size_t pi = 0; pi < h->phases.size() && st == FAV_OK; ++pi) {
                 const long long dom = h->phases[pi].suffix ? (long long)n * h->T_eff : n;
-                fav_status st = run_chunks(h, pi, images, layout, n, first_index, w.stream, 0, dom, w.act, &w);
-                if (st != FAV_OK) return st;
+                st = run_chunks(h, pi, images, layout, n, first_index, w.stream, 0, dom, w.act, &w);
             }
-            HIP_TRY(h, hipEventRecord(w.done, w.stream));
+            HIP_KEEP(h, st, hipEventRecord(w.done, w.stream));
+            HIP_KEEP(h, st, hipStreamWaitEvent(s, w.done, 0));
         }
-        for (int member = 0; member < h->n_members; ++member) HIP_TRY(h, hipStreamWaitEvent(s, h->mws[member].done, 0));
+        if (st != FAV_OK) return st;
     } else
     for (int member = 0; member < h->n_members; ++member) {
     for (auto& L : h->layers) { L.w = L.w_m[member]; L.b = L.b_m[member]; }
@@ -1665,24 +1709,26 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
         HIP_TRY(h, hipStreamWaitEvent(h->stream_a, h->ev_fork, 0));
         HIP_TRY(h, hipStreamWaitEvent(h->stream_b, h->ev_fork, 0));
         size_t ci = 0;
-        for (long long v0 = 0; v0 < dom; v0 += step, ++ci) {
+        fav_status st = FAV_OK;         // nothing returns between the fork and the join
+        for (long long v0 = 0; v0 < dom && st == FAV_OK; v0 += step, ++ci) {
             const long long v1 = std::min(dom, v0 + step);
-            fav_status st = run_chunks(h, pa, images, layout, n, first_index, h->stream_a, v0, v1, h->act);
-            if (st != FAV_OK) return st;
+            st = run_chunks(h, pa, images, layout, n, first_index, h->stream_a, v0, v1, h->act);
+            if (st != FAV_OK) break;
             if (ci >= h->ev_chunk.size()) {
-                hipEvent_t e;
-                HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                hipEvent_t e = nullptr;
+                HIP_KEEP(h, st, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                if (st != FAV_OK) break;
                 h->ev_chunk.push_back(e);
             }
-            HIP_TRY(h, hipEventRecord(h->ev_chunk[ci], h->stream_a));
-            HIP_TRY(h, hipStreamWaitEvent(h->stream_b, h->ev_chunk[ci], 0));
-            st = run_chunks(h, pb, images, layout, n, first_index, h->stream_b, v0, v1, h->act2);
-            if (st != FAV_OK) return st;
+            HIP_KEEP(h, st, hipEventRecord(h->ev_chunk[ci], h->stream_a));
+            HIP_KEEP(h, st, hipStreamWaitEvent(h->stream_b, h->ev_chunk[ci], 0));
+            if (st == FAV_OK) st = run_chunks(h, pb, images, layout, n, first_index, h->stream_b, v0, v1, h->act2);
         }
-        HIP_TRY(h, hipEventRecord(h->ev_join_a, h->stream_a));
-        HIP_TRY(h, hipEventRecord(h->ev_join_b, h->stream_b));
-        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_a, 0));
-        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join_b, 0));
+        HIP_KEEP(h, st, hipEventRecord(h->ev_join_a, h->stream_a));
+        HIP_KEEP(h, st, hipEventRecord(h->ev_join_b, h->stream_b));
+        HIP_KEEP(h, st, hipStreamWaitEvent(s, h->ev_join_a, 0));
+        HIP_KEEP(h, st, hipStreamWaitEvent(s, h->ev_join_b, 0));
+        if (st != FAV_OK) return st;
     }
     }
     if (!h->vit) h->phase_out.back() = h->logits;
@@ -1697,6 +1743,7 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     h->last_n = n;
     return FAV_OK;
 }
+}  // namespace
 
 fav_status fav_classify(fav_handle* h, const void* images, int32_t n, int32_t layout, int32_t* labels, float* conf,
                         void* stream) {
@@ -1740,9 +1787,11 @@ fav_status fav_get_logits(fav_handle* h, float* out, int32_t* t_out, int32_t* n_
     if (t_out) *t_out = h->last_T;
     if (n_out) *n_out = h->last_n;
     if (out) {
+        if (fav_status st = wait_last_use(h, (hipStream_t)stream)) return st;
         HIP_TRY(h, hipMemcpy2DAsync(out, (size_t)h->cfg.num_classes * 4, h->logits, (size_t)h->cpad * 4,
                                     (size_t)h->cfg.num_classes * 4, (size_t)h->last_T * h->last_n,
                                     hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        mark_last_use(h, (hipStream_t)stream);
     }
     return FAV_OK;
 }

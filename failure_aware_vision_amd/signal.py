@@ -90,6 +90,14 @@ class SignalAnalyzerHIP:
         self._frame_count = 0
         self._consecutive_frozen = 0
 
+    def save_state(self):
+        """Snapshot of the temporal state (previous gray plane, frame count, frozen run), for callers that must be
+        able to undo a launch_stats / score_stats pair whose device work failed (Backend.analyze_frame)."""
+        return (self._prev_gray, self._frame_count, self._consecutive_frozen)
+
+    def restore_state(self, state):
+        self._prev_gray, self._frame_count, self._consecutive_frozen = state
+
     def launch_stats(self, frames):
         """Queue the fused statistics pass for uint8 [n, H, W, 3] frames (numpy or CUDA tensor) on the current
         stream; returns the device byte tensor holding n fav_signal_stats records (no host sync)."""

@@ -41,8 +41,8 @@ VIT_CFG = {  # embed dim, depth, heads (64-wide), MLP width, patch, default inpu
     3: dict(dim=128, depth=2, heads=2, mlp=256, patch=16, in_hw=(64, 64)),
 }
 _ARCH = {
-    0: dict(block="basic", depths=(2, 2, 2, 2), planes=(64, 128, 256, 512), stem="cifar", calib_hw=32),
-    1: dict(block="bottleneck", depths=(3, 4, 6, 3), planes=(64, 128, 256, 512), stem="imagenet", calib_hw=96),
+    0: dict(block="basic", depths=(2, 2, 2, 2), planes=(64, 128, 256, 512), stem="cifar", calib_hw=32, n_calib=16),
+    1: dict(block="bottleneck", depths=(3, 4, 6, 3), planes=(64, 128, 256, 512), stem="imagenet", calib_hw=224, n_calib=8),
 }
 DEFAULT_MEAN = (0.485, 0.456, 0.406)
 DEFAULT_STD = (0.229, 0.224, 0.225)
@@ -118,6 +118,9 @@ def _conv64(x, w, stride, pad):
     """float64 NHWC conv by im2col (calibration only)."""
     b, h, ww, c = x.shape
     co, kh, kw, _ = w.shape
+    if kh == 1 and kw == 1 and pad == 0:
+        xs = x[:, ::stride, ::stride]
+        return (xs.reshape(-1, c) @ w.reshape(co, c).T.astype(np.float64)).reshape(xs.shape[:3] + (co,))
     ho = (h + 2 * pad - kh) // stride + 1
     wo = (ww + 2 * pad - kw) // stride + 1
     xp = np.zeros((b, h + 2 * pad, ww + 2 * pad, c))
@@ -173,62 +176,123 @@ def make_synthetic_vit(arch="vit_b16", seed: int = 1, num_classes: int = 1000, i
     return blob, info
 
 
-def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = None,
-                   mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 6.0, n_calib: int = 16,
-                   calib_dropout_p: float = 0.1):
-    """Returns (blob bytes, info dict).
+def tv_names(arch: int, specs):
+    """torchvision state_dict prefixes for the blob-order layer list -> [(conv_name, bn_name | None)]."""
+    a = _ARCH[arch]
+    names, seen = [], {}
+    for sp in specs:
+        if sp["role"] == "stem":
+            names.append(("conv1", "bn1"))
+        elif sp["role"] == "fc":
+            names.append(("fc", None))
+        else:
+            blk, stage = sp["block"], 0
+            while blk >= a["depths"][stage]:
+                blk -= a["depths"][stage]; stage += 1
+            p = f"layer{stage + 1}.{blk}."
+            if sp["role"] == "down":
+                names.append((p + "downsample.0", p + "downsample.1"))
+            else:
+                k = seen[p] = seen.get(p, 0) + 1
+                names.append((f"{p}conv{k}", f"{p}bn{k}"))
+    return names
 
-    The calibration batch is run twice through every layer — once as is, once with
-    Bernoulli(calib_dropout_p) dropout on every residual-block output — so the folded
-    statistics suit both the deterministic pass and the MC-Dropout passes (as a
-    network trained with dropout would)."""
+
+def _fold(w_ohwi, gamma, beta, mean, var, eps):
+    """fp32 parameters -> (bf16 weight bits [O,kh,kw,I], fp32 bias): the fold `from_state_dict` applies."""
+    w, gamma, beta, mean, var = (np.asarray(t, np.float64) for t in (w_ohwi, gamma, beta, mean, var))
+    scale = gamma / np.sqrt(var + eps)
+    return _bf16((w * scale[:, None, None, None]).astype(np.float32)), (beta + (0.0 - mean) * scale).astype(np.float32)
+
+
+def _head_from_features(rng, feat_det, feat_mc, num_classes, logit_std, k, gamma=0.5):
+    """The classifier of a synthetic checkpoint -> (W fp32 [classes, C], bias-centre fp64 [C]).
+
+    An untrained network's pooled features move far more with the *regime* (deterministic pass vs a dropout
+    sample: the shift q1 is longer than the feature vector itself) and with the dropout noise (white, ~2x the
+    between-frame spread in norm) than with the frame's content, so a dense random head labels frames by
+    regime and noise.  A trained head reads the directions that carry content; this one does too: the top-k
+    principal directions of the deterministic calibration features (deflated by q1, partially whitened),
+    mixed into `num_classes` logits by a seeded Gaussian matrix."""
+    m_det, m_mc = feat_det.mean(axis=0), feat_mc.mean(axis=0)
+    q1 = m_mc - m_det
+    q1 = q1 / max(np.linalg.norm(q1), 1e-30)
+    x = feat_det - m_det
+    x = x - np.outer(x @ q1, q1)
+    _, s, vt = np.linalg.svd(x, full_matrices=False)
+    k = int(min(k, max(1, len(x) - 2)))
+    pcs = vt[:k].copy()
+    for i in range(k):                                    # fix the sign (an SVD leaves it open)
+        if pcs[i, np.argmax(np.abs(pcs[i]))] < 0:
+            pcs[i] = -pcs[i]
+    sig = np.maximum(s[:k] / np.sqrt(len(x)), 1e-12)
+    mix = rng.standard_normal((num_classes, k))
+    w = (mix / sig ** gamma) @ pcs
+    centre = 0.5 * (m_det + m_mc)
+    raw = np.concatenate([feat_det - centre, feat_mc - centre]) @ w.T
+    g = float(_bf16_f32(np.float32(logit_std / max(raw.std(), 1e-12))))
+    return (w * g).astype(np.float32), centre
+
+
+def make_synthetic_state_dict(arch="resnet50", seed: int = 1, num_classes: int | None = None,
+                              mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 12.0, n_calib: int | None = None,
+                              calib_dropout_p: float = 0.1, head_rank: int = 4):
+    """The synthetic checkpoint as an fp32 ``state_dict`` in torchvision naming (numpy arrays: conv OIHW,
+    BatchNorm weight / bias / running_mean / running_var, fc) -> (state_dict, meta).  This is the checkpoint:
+    ``make_synthetic`` is its fold (``from_state_dict``), and ``tests/torch_models.ResNet`` loads it as is.
+
+    The calibration frames (at the deployment resolution: half of them with Gaussian noise of severities 1..5)
+    run through every layer twice - as they are and with Bernoulli(calib_dropout_p) dropout on every
+    residual-block output - so the running statistics suit both the deterministic pass and the MC-Dropout
+    samples, as those of a network trained with dropout would.  Statistics are quantised to bf16 so the
+    checkpoint is bit-identical on any machine (BLAS summation order only moves them by ~1e-16 relative)."""
     arch = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
     a = _ARCH[arch]
     if num_classes is None:
         num_classes = 1000 if arch == 1 else 10
+    if n_calib is None:
+        n_calib = a["n_calib"]
     specs = layer_specs(arch, num_classes)
-    rng = np.random.default_rng([int(seed), arch, 0x77])
+    names = tv_names(arch, specs)
+    rng = np.random.default_rng([int(seed), arch, 0x78])
     hw = a["calib_hw"]
     frames = synth.synthetic_frames_u8(n_calib, hw, hw, seed=0xCA11B, start_id=0)
-    # half of the calibration frames carry Gaussian noise (severities 1..5) so the
-    # statistics also cover the corrupted regime the detector is meant for
     x01 = frames.astype(np.float64) / 255.0
     for i in range(n_calib // 2, n_calib):
         x01[i] = synth.gaussian_noise_f32(frames[i:i + 1], 1 + i % 5, seed=0xCA11B, start_id=i)[0]
     x = (x01 - np.asarray(mean)) / np.asarray(std)
     x = np.concatenate([x, x], axis=0)          # second half: the dropout pass
     drop_rng = np.random.default_rng([int(seed), arch, 0xD0])
+    eps = 1e-5
+    sd = {}
 
-    folded = []  # (w_bf16_bits, b_fp32)
-
-    def make_layer(spec, inp):
+    def make_layer(spec, name, inp):
+        conv, bn = name
         fan_in = spec["kh"] * spec["kw"] * spec["cin"]
         gain = 1.0 if spec["role"] == "down" else 2.0
         w = rng.standard_normal((spec["cout"], spec["kh"], spec["kw"], spec["cin"])) * np.sqrt(gain / fan_in)
         if spec["role"] == "stem" and spec["kh"] >= 5:
-            # smooth (low-pass) first-layer filters, as a trained stem has: white pixel noise
-            # then excites the network far less than image content does, which keeps the
-            # labels of noise-corrupted frames diverse instead of collapsing to one class
+            # smooth (low-pass) first-layer filters, as a trained stem has: white pixel noise then excites the
+            # network far less than image content does
             k1 = np.array([1.0, 4.0, 6.0, 4.0, 1.0]) / 16.0
             for ax in (1, 2):
                 w = np.apply_along_axis(lambda v: np.convolve(v, k1, mode="same"), ax, w)
-        acc = _conv64(inp, w, spec["stride"], spec["pad"])
-        mu = _bf16_f32(acc.mean(axis=(0, 1, 2))).astype(np.float64)
-        var = _bf16_f32(acc.var(axis=(0, 1, 2))).astype(np.float64)
+        w32 = w.astype(np.float32)
+        acc = _conv64(inp, w32.astype(np.float64), spec["stride"], spec["pad"])
+        mu = _bf16_f32(acc.mean(axis=(0, 1, 2)))
+        var = _bf16_f32(acc.var(axis=(0, 1, 2)))
         gamma = {"stem": 1.0, "mid": 1.0, "last": 0.25, "down": 0.7}[spec["role"]]
-        gam = gamma * (1.0 + 0.1 * rng.standard_normal(spec["cout"]))
-        beta = (0.25 if spec["role"] in ("stem", "mid") else 0.1) * rng.standard_normal(spec["cout"])
-        scale = gam / np.sqrt(var + 1e-5)
-        wq = _bf16((w * scale[:, None, None, None]).astype(np.float32))
-        bq = (beta - mu * scale).astype(np.float32)
+        gam = (gamma * (1.0 + 0.1 * rng.standard_normal(spec["cout"]))).astype(np.float32)
+        beta = ((0.25 if spec["role"] in ("stem", "mid") else 0.1) * rng.standard_normal(spec["cout"])).astype(np.float32)
+        sd[conv + ".weight"] = np.ascontiguousarray(w32.transpose(0, 3, 1, 2))
+        sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"], sd[bn + ".running_var"] = gam, beta, mu, var
+        wq, bq = _fold(w32, gam, beta, mu, var, eps)
         wf = (wq.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
-        out = _conv64(inp, wf, spec["stride"], spec["pad"]) + bq.astype(np.float64)
-        folded.append((wq, bq))
-        return out
+        return _conv64(inp, wf, spec["stride"], spec["pad"]) + bq.astype(np.float64)
 
-    it = iter(specs)
-    spec = next(it)
-    act = np.maximum(make_layer(spec, x), 0.0)
+    it = iter(zip(specs, names))
+    spec, name = next(it)
+    act = np.maximum(make_layer(spec, name, x), 0.0)
     if a["stem"] == "imagenet":  # 3x3/2 max pool, pad 1
         b_, h_, w_, c_ = act.shape
         ho, wo = (h_ - 1) // 2 + 1, (w_ - 1) // 2 + 1
@@ -236,40 +300,41 @@ def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = Non
         xp[:, 1:1 + h_, 1:1 + w_] = act
         act = np.max(np.stack([xp[:, r:r + 2 * ho:2, s:s + 2 * wo:2] for r in range(3) for s in range(3)]), axis=0)
     nmain = 3 if a["block"] == "bottleneck" else 2
-    spec = next(it)
+    spec, name = next(it)
     while spec["role"] != "fc":
         blk = spec["block"]
         h = act
-        main = [spec] + [next(it) for _ in range(nmain - 1)]
-        for sp in main[:-1]:
-            h = np.maximum(make_layer(sp, h), 0.0)
-        branch = make_layer(main[-1], h)
-        spec = next(it)
+        main = [(spec, name)] + [next(it) for _ in range(nmain - 1)]
+        for sp, nm in main[:-1]:
+            h = np.maximum(make_layer(sp, nm, h), 0.0)
+        branch = make_layer(main[-1][0], main[-1][1], h)
+        spec, name = next(it)
         idn = act
         if spec["role"] == "down" and spec["block"] == blk:
-            idn = make_layer(spec, act)
-            spec = next(it)
+            idn = make_layer(spec, name, act)
+            spec, name = next(it)
         act = np.maximum(branch + idn, 0.0)
         if calib_dropout_p > 0:
             keep = drop_rng.random(act[n_calib:].shape) >= calib_dropout_p
             act[n_calib:] = np.where(keep, act[n_calib:] / (1.0 - calib_dropout_p), 0.0)
     feat = act.mean(axis=(1, 2))  # [2*n_calib, C]
-    # classifier: zero-mean rows (cancels the common-mode of the all-positive
-    # features), gain chosen so calibration logits have the requested spread,
-    # bias chosen so no class wins by default.
-    w = rng.standard_normal((num_classes, feat.shape[1]))
-    w -= w.mean(axis=1, keepdims=True)
-    raw = (feat - feat.mean(axis=0, keepdims=True)) @ w.T
-    g = float(_bf16_f32(np.float32(logit_std / max(raw.std(), 1e-12))))
-    wq = _bf16((w * g).astype(np.float32))
+    w32, centre = _head_from_features(rng, feat[:n_calib], feat[n_calib:], num_classes, logit_std, head_rank)
+    wq = _bf16(w32)
     wf = (wq.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
-    fmean = _bf16_f32(feat.mean(axis=0)).astype(np.float64)
-    bq = (-(fmean @ wf.T)).astype(np.float32)
-    folded.append((wq.reshape(num_classes, 1, 1, -1), bq))
+    fcentre = _bf16_f32(centre).astype(np.float64)
+    sd["fc.weight"] = w32
+    sd["fc.bias"] = (-(fcentre @ wf.T)).astype(np.float32)     # centred on what the bf16 weights see
+    meta = dict(arch=arch, num_classes=num_classes, seed=seed, bn_eps=eps, mean=tuple(mean), std=tuple(std),
+                calib_hw=hw, n_calib=n_calib)
+    return sd, meta
 
-    blob = pack_blob(arch, num_classes, specs, folded)
-    info = dict(arch=arch, num_classes=num_classes, n_layers=len(specs), seed=seed,
-                sha256=hashlib.sha256(blob).hexdigest(), mean=tuple(mean), std=tuple(std))
+
+def make_synthetic(arch="resnet50", seed: int = 1, num_classes: int | None = None,
+                   mean=DEFAULT_MEAN, std=DEFAULT_STD, **kw):
+    """Returns (blob bytes, info dict): the fold of ``make_synthetic_state_dict`` (same arguments)."""
+    sd, meta = make_synthetic_state_dict(arch, seed, num_classes, mean, std, **kw)
+    blob, info = from_state_dict(meta["arch"], sd, bn_eps=meta["bn_eps"], mean=mean, std=std)
+    info.update(seed=seed, source="synthetic")
     return blob, info
 
 
@@ -370,27 +435,10 @@ def from_state_dict(arch, sd, num_classes: int | None = None, bn_eps: float = 1e
         hw = int(round((ntok - 1) ** 0.5)) * P
         info_extra = dict(in_hw=(hw, hw), n_tokens=ntok)
     else:
-        a = _ARCH[aid]
         ncls = int(_np(sd["fc.weight"]).shape[0])
-        nmain = 3 if a["block"] == "bottleneck" else 2
-        for sp in layer_specs(aid, ncls):
-            if sp["role"] == "stem":
-                wq, b = _fold_conv_bn(sd, "conv1", "bn1", bn_eps)
-            elif sp["role"] == "fc":
-                wq, b = _linear(sd, "fc")
-            else:
-                blk, stage = sp["block"], 0
-                while blk >= a["depths"][stage]:
-                    blk -= a["depths"][stage]; stage += 1
-                p = f"layer{stage + 1}.{blk}."
-                if sp["role"] == "down":
-                    wq, b = _fold_conv_bn(sd, p + "downsample.0", p + "downsample.1", bn_eps)
-                else:
-                    k = sum(1 for q in specs if q.get("_p") == p) + 1     # conv index inside the block, blob order
-                    if k > nmain:
-                        raise ValueError("layer order mismatch")
-                    wq, b = _fold_conv_bn(sd, f"{p}conv{k}", f"{p}bn{k}", bn_eps)
-                    sp = dict(sp, _p=p)
+        lspecs = layer_specs(aid, ncls)
+        for sp, (conv, bn) in zip(lspecs, tv_names(aid, lspecs)):
+            wq, b = _linear(sd, conv) if bn is None else _fold_conv_bn(sd, conv, bn, bn_eps)
             if wq.shape != (sp["cout"], sp["kh"], sp["kw"], sp["cin"]):
                 raise ValueError(f"{sp['role']} of block {sp['block']}: checkpoint tensor is {wq.shape}, the architecture expects "
                                  f"{(sp['cout'], sp['kh'], sp['kw'], sp['cin'])} (ResNet-50 must be v1.5)")

@@ -208,10 +208,11 @@ def test_error_behaviour(r18_blob):
     out = be.analyze_frame(frame)
     assert set(out) == {"anomaly_score", "vision_status", "metrics"}
     assert 0.0 <= out["anomaly_score"] <= 1.0 and out["vision_status"].startswith("VISION_")
-    assert abs(out["anomaly_score"] - (1 - out["metrics"]["confidence"])) < 1e-3
+    assert abs(out["anomaly_score"] - (1 - out["metrics"]["classifier"]["confidence"])) < 1e-3
+    assert {"blur", "brightness", "freeze", "entropy", "raw"} <= set(out["metrics"])      # main.py:171-177 reads these
     assert be.analyze_frame(frame, status_provider=lambda f: "VISION_FROZEN")["vision_status"] == "VISION_FROZEN"
-    bad = be.analyze_frame(np.zeros((16, 16, 3), np.uint8))      # wrong size: the seam's "no ML score" convention
-    assert bad["anomaly_score"] is None and bad["metrics"] == {}
+    with pytest.raises(ValueError):                               # wrong size: a caller bug, not a quiet "VISION_OK"
+        be.analyze_frame(np.zeros((16, 16, 3), np.uint8))
     be.close()
 
 
@@ -232,15 +233,37 @@ def test_one_call_scorer_at_the_seam(r50_blob):
         ref = orc.analyze_frame(fr)
         assert set(out) == {"anomaly_score", "vision_status", "metrics"}
         assert out["vision_status"] == ref["vision_status"], i
-        sig = out["metrics"]["signal"]
-        assert abs(sig["anomaly_score"] - ref["anomaly_score"]) <= 2e-6
-        assert sig["raw"]["mean_brightness"] == ref["metrics"]["raw"]["mean_brightness"]
+        # the keys the reference's loop reads right after the call (main.py:163-177)
+        assert abs(out["metrics"]["rule_anomaly_score"] - ref["anomaly_score"]) <= 2e-6
+        assert out["metrics"]["raw"]["mean_brightness"] == ref["metrics"]["raw"]["mean_brightness"]
+        for key in ("blur", "brightness", "freeze", "entropy"):
+            assert abs(out["metrics"][key] - ref["metrics"][key]) <= 1e-4, key
         labels, conf, fail, score = ref_be.classify_detect(fr[None])          # the classifier alone, same frame
-        assert out["metrics"]["label"] == int(labels[0]) and out["anomaly_score"] == round(float(score[0]), 6)
+        assert out["metrics"]["classifier"]["label"] == int(labels[0]) and out["anomaly_score"] == round(float(score[0]), 6)
         state = eng.update(out["vision_status"], out["anomaly_score"], 1 / 30)
+        state["anomaly_score"] = round(out["anomaly_score"], 6)               # main.py:169 (a number, never None)
         seen.add(out["vision_status"])
     assert seen == {"VISION_OK", "VISION_FROZEN", "VISION_BLANK", "VISION_CORRUPTED"}
     assert 0.0 <= state["reliability"] <= 1.0
     be.reset()
-    assert be.analyze_frame(frames[0])["metrics"]["signal"]["raw"]["frame_diff"] == 10.0   # reset cleared the previous frame
+    assert be.analyze_frame(frames[0])["metrics"]["raw"]["frame_diff"] == 10.0   # reset cleared the previous frame
+    # caller bugs are raised, not swallowed
+    with pytest.raises(ValueError):
+        be.analyze_frame(frames[0][:100])
+    with pytest.raises(TypeError):
+        be.analyze_frame(frames[0].astype(np.float32))
+    # a failure of the device path does not read as a healthy frame, and leaves the rule scorer's state alone
+    be.analyze_frame(frames[1])
+    before = be._rules.save_state()
+    real = be.classify_detect
+    def boom(*a, **k):
+        raise FavError(5, "injected")
+    be.classify_detect = boom
+    bad = be.analyze_frame(frames[2])
+    be.classify_detect = real
+    assert bad["vision_status"] == "VISION_CORRUPTED" and bad["anomaly_score"] == 1.0 and "injected" in bad["metrics"]["error"]
+    assert round(bad["anomaly_score"], 6) == 1.0 and "blur" in bad["metrics"]
+    after = be._rules.save_state()
+    assert after[0] is before[0] and after[1:] == before[1:]
+    eng.update(bad["vision_status"], bad["anomaly_score"], 1 / 30)
     be.close(); ref_be.close()

@@ -2,6 +2,7 @@
 and the NumPy restatement against torch.nn.functional on CPU (SURVEY.md §8c:
 the reference pins nothing on this path, so the oracle is cross-checked against
 an independent implementation instead)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -185,5 +186,41 @@ def test_bf16_mfma_model_reproduces_recorded_instruction_outputs():
         out = np.empty_like(D)
         lib.fav_bf16mfma_replay(A.ctypes.data, B.ctypes.data, C.ctypes.data, out.ctypes.data, A.shape[0])
         assert np.array_equal(out, D), n
+        # the AVX-512 form of the same arithmetic (what the fixture generators run where the CPU has it)
+        out2 = np.full_like(D, np.nan)
+        lib.fav_bf16mfma_replay_avx512.restype = ctypes.c_int
+        lib.fav_bf16mfma_replay_avx512.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int]
+        if lib.fav_bf16mfma_replay_avx512(A.ctypes.data, B.ctypes.data, C.ctypes.data, out2.ctypes.data, A.shape[0]) == 0:
+            assert np.array_equal(out2.view(np.uint32), D.view(np.uint32)), n + " (AVX-512 form)"
         total += D.size
     assert total > 100000
+
+
+def test_bf16_mfma_model_vector_form_equals_scalar_form_on_convolutions():
+    """The AVX-512 path of fav_bf16mfma_conv_acc against the scalar one (FAV_ORACLE_SCALAR=1 in a child
+    process: the choice is cached per process), on activations with ReLU zeros, wide-range values and padding."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import fav_oracle as O
+rng = np.random.default_rng(7)
+outs = []
+for (b, h, c, n, kh, s, p) in ((2, 9, 64, 40, 3, 1, 1), (1, 8, 128, 256, 1, 1, 0), (2, 10, 64, 64, 3, 2, 1)):
+    x = rng.standard_normal((b, h, h, c)).astype(np.float32) * np.exp2(rng.integers(-12, 6, (b, h, h, c))).astype(np.float32)
+    x = np.where(rng.random(x.shape) < 0.45, 0.0, x).astype(np.float32)
+    w = (rng.standard_normal((n, kh, kh, c)) * np.exp2(rng.integers(-6, 2, (n, 1, 1, 1)))).astype(np.float32)
+    w[:, :, :, ::7] = 0
+    outs.append(O.conv_acc_exact(O.bf16_round(x), O.bf16_round(w), kh, kh, s, p, mode="mfma"))
+np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("vector", {}), ("scalar", {"FAV_ORACLE_SCALAR": "1"})):
+            out = os.path.join(td, tag + ".npy")
+            subprocess.check_call([sys.executable, "-c", code, out], env={**os.environ, **env})
+            res[tag] = np.load(out)
+    assert np.isfinite(res["scalar"]).all() and np.abs(res["scalar"]).max() > 0
+    assert np.array_equal(res["vector"].view(np.uint32), res["scalar"].view(np.uint32))
