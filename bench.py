@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the failure-aware classification path.
+"""bench.py — benchmark of the failure-aware classification path.
 
-Workload (BASELINE.json `metric`, configs[2]): ResNet-50, MC-Dropout T=30 (dropout
+Default workload (BASELINE.json `metric`, configs[2]): ResNet-50, MC-Dropout T=30 (dropout
 after every residual block, p=0.1 — the `all_blocks` policy, 225.1 GFLOP per
 frame algorithmic with the deterministic prefix computed once), 224x224 frames
 with ImageNet-C style Gaussian noise severity 3, batch 256 per GPU.  A "step" is
 one classify() of one batch: frames resident in HBM -> (label, confidence) per
 frame.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every
-rank classifies its own 256-frame shard of a 256*N global batch (weak scaling) and
-the packed (label, confidence) records are all-gathered.
+rank classifies its own shard, the confidence head writes its packed (label, confidence)
+records straight into the all-gather send slot and one all-gather moves them.
+
+`--config` selects another BASELINE.json config as the measured line (same JSON contract,
+same sharding + all-gather, its own `roofline`):
+  mc30    configs[2]  ResNet-50 MC-Dropout T=30, 256 frames per GPU      (weak scaling; the default / headline)
+  single  configs[1]  ResNet-50 single pass, 256 frames per GPU           (weak scaling)
+  ens5    configs[3]  5-member ResNet-50 ensemble, global batch 256 / N   (strong scaling)
+  vit     configs[4]  ViT-B/16 + temperature entropy, global batch 512 / N (strong scaling)
+Without `--config` the line is the headline's, with the other configs' per-GPU shares under `extra`.
 
 `python bench.py --gpus N` with no torchrun environment starts the N ranks itself
 (a child `python -m torch.distributed.run ... bench.py`), BEFORE this process has
@@ -37,6 +45,8 @@ VIT_B16_GMAC = 17.56
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 KERNEL_SOURCES = ("failure_aware_vision_amd/csrc/fav_kernels.hpp", "failure_aware_vision_amd/csrc/fav.hip")
+CONV_KERNELS = ("fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel + fav::entry_reduce_kernel "
+                "(every conv / fc launch of the timed steps)")
 
 
 def algorithmic_gflop_per_frame(policy: str, T: int) -> float:
@@ -104,18 +114,59 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(blob, args, T, policy):
-    """The oracle's torch-CPU port (fp32 MKL-DNN, same weights, corruption, masks and prefix caching) on a
-    bounded sample of the same workload, timed on this host's cores: `cpu_frames` frames x T samples, the T
-    suffix passes stacked into one batch (what a many-core host runs best), one warm-up call - which also
-    generates the Philox masks, so they are inputs, outside the timed region - then `cpu_repeats` timed calls."""
+def _cpu_threads(args, torch):
+    threads = args.cpu_threads if args.cpu_threads > 0 else min(torch.get_num_threads(), effective_cpus())
+    torch.set_num_threads(threads)
+    return torch.get_num_threads()
+
+
+def cpu_baseline(args, T, policy):
+    """The headline algorithm as a PyTorch-CPU user would run it (oracle/torch_fp32.py): the synthetic checkpoint as a
+    plain fp32 nn.Module (BatchNorm un-folded, no bf16 anywhere, the library's fp32 MKL-DNN convolutions), the
+    deterministic prefix once, the T dropout samples of the suffix as one stacked batch with F.dropout masks from
+    torch's own generator, mean of softmax.  Bounded sample: `cpu_frames` frames (b = 32), one
+    warm-up call on a quarter of them, then timed calls until `cpu_repeats` are done or 30 s are spent."""
+    import numpy as np
+    import torch
+    from failure_aware_vision_amd import synth, weights
+    from oracle import torch_fp32 as TF
+    n = args.cpu_frames
+    threads = _cpu_threads(args, torch)
+    net, meta = TF.load_synthetic("resnet50", seed=1)
+    x = synth.gaussian_noise_f32(synth.synthetic_frames_u8(n, 224, 224, seed=21), 3, seed=3)
+    xn = (x - np.asarray(meta["mean"], np.float32)) / np.asarray(meta["std"], np.float32)
+    xt = torch.from_numpy(np.ascontiguousarray(xn.transpose(0, 3, 1, 2))).contiguous(memory_format=torch.channels_last)
+    sm = weights.site_mask_for(1, policy) if policy != "none" else 0
+    gen_p = round(args.dropout_p * 256) / 256.0                   # the GPU path draws 8-bit thresholds
+    t0 = time.perf_counter()
+    TF.mc_dropout_probs(net, xt[:max(1, n // 4)], T, sm, gen_p)
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < max(1, args.cpu_repeats) and (not times or sum(times) < 30.0):
+        t0 = time.perf_counter()
+        TF.mc_dropout_probs(net, xt, T, sm, gen_p)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    gf = algorithmic_gflop_per_frame(policy, T)
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "variant": "fp32_module", "batch": n, "repeats": len(times), "seconds": times, "warmup_seconds": warm,
+            "gflops": n * gf / dt, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "usable_cpus": effective_cpus(),
+            "sample": f"{n} frames x T={T} ({policy}) = {n * T} suffix passes in one stacked batch through the fp32 nn.Module "
+                      f"of oracle/torch_fp32.py (BatchNorm un-folded, F.dropout masks, torch {torch.__version__} MKL-DNN) on "
+                      f"{threads} threads; 1 warm-up call on {max(1, n // 4)} frames + {len(times)} timed calls, median {dt:.2f} s"}
+
+
+def cpu_baseline_oracle_port(blob, args, T, policy):
+    """Second CPU figure, the oracle's torch-CPU port (oracle/torch_cpu.py): the GPU path's own numerical contract on the
+    CPU - bf16 rounding at every layer boundary and the SAME Philox masks (generated in the warm-up call: inputs, not
+    timed) - on `cpu_port_frames` frames.  It pays rounding work a PyTorch user would not; kept for continuity."""
     import torch
     from failure_aware_vision_amd import synth, weights
     from oracle import fav_oracle as O
     from oracle import torch_cpu as TC
-    n = args.cpu_frames
-    threads = args.cpu_threads if args.cpu_threads > 0 else min(torch.get_num_threads(), effective_cpus())
-    torch.set_num_threads(threads)
+    n = args.cpu_port_frames
+    threads = _cpu_threads(args, torch)
     frames = synth.gaussian_noise_f32(synth.synthetic_frames_u8(n, 224, 224, seed=21), 3, seed=3)
     model = O.parse_blob(blob)
     net = TC.TorchNet(model)
@@ -125,67 +176,169 @@ def cpu_baseline(blob, args, T, policy):
     TC.classify(model, frames, cfg, net=net, stack_samples=True)          # warm-up + mask generation
     warm = time.perf_counter() - t0
     times = []
-    for _ in range(max(1, args.cpu_repeats)):
+    for _ in range(2):
         t0 = time.perf_counter()
         TC.classify(model, frames, cfg, net=net, stack_samples=True)
         times.append(time.perf_counter() - t0)
-        if sum(times) > 45.0:                                               # keep the default run within minutes
+        if sum(times) > 15.0:
             break
     dt = statistics.median(times)
-    gf = algorithmic_gflop_per_frame(policy, T)
-    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "batch": n, "repeats": len(times), "seconds": times, "warmup_seconds": warm,
-            "gflops": n * gf / dt, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
-            "usable_cpus": effective_cpus(),
-            "sample": f"{n} frames x T={T} ({policy}) = {n * T} suffix passes in one stacked batch, oracle/torch_cpu.py "
-                      f"fp32 MKL-DNN on {torch.get_num_threads()} threads; 1 warm-up call (also generates the Philox "
-                      f"masks: inputs, not timed) + {len(times)} timed calls, median {dt:.2f} s"}
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port", "variant": "oracle_port_bf16_boundaries",
+            "batch": n, "repeats": len(times), "warmup_seconds": warm, "gflops": n * algorithmic_gflop_per_frame(policy, T) / dt}
 
 
-def secondary_configs(blob, args, torch, synth, weights, Backend):
-    """Cheap driver-timed lines for the other BASELINE configs (1 GPU, after the headline's timed region):
-    configs[1] single pass, configs[3]'s per-GPU share (5 members, 32 frames), configs[4]'s per-GPU share
-    (ViT-B/16, 64 frames).  fps = frames / wall time of `steps` calls bracketed by synchronize()."""
-    out = {}
+# --------------------------------------------------------------------------------------------------------------
+# The measured configurations
+# --------------------------------------------------------------------------------------------------------------
+def config_table(args):
+    T = args.samples if args.policy != "none" else 1
+    return {
+        "mc30": dict(arch="resnet50", scaling="weak", per_gpu=args.batch, T=T, policy=args.policy,
+                     metric="frames/sec, ResNet-50 MC-Dropout T=%d 224x224 batch=%d" % (T, args.batch),
+                     workload="BASELINE configs[2]: ResNet-50 v1.5 + MC-Dropout T=%d (%s, p=%.2f), 224x224x3 fp32 "
+                              "frames with Gaussian noise severity 3, batch %d per GPU, synthetic frames and "
+                              "seeded synthetic weights" % (T, args.policy, args.dropout_p, args.batch),
+                     gflop=algorithmic_gflop_per_frame(args.policy, T), bound="hbm"),
+        "single": dict(arch="resnet50", scaling="weak", per_gpu=args.batch, T=1, policy="none",
+                       metric="frames/sec, ResNet-50 single pass 224x224 batch=%d" % args.batch,
+                       workload="BASELINE configs[1]: ResNet-50 v1.5 single deterministic pass, max-softmax confidence, 224x224x3 "
+                                "fp32 frames with Gaussian noise severity 3, batch %d per GPU" % args.batch,
+                       gflop=2 * RESNET50_GMAC, bound="hbm"),
+        "ens5": dict(arch="resnet50", scaling="strong", global_batch=256, T=1, policy="none", members=5,
+                     metric="frames/sec, 5-member ResNet-50 deep ensemble 224x224 global batch=256",
+                     workload="BASELINE configs[3]: 5 independently seeded ResNet-50 members, mean of member softmax, global "
+                              "batch 256 sharded over the GPUs (every rank runs all 5 members on its shard)",
+                     gflop=5 * 2 * RESNET50_GMAC, bound="mfma"),
+        "vit": dict(arch="vit_b16", scaling="strong", global_batch=512, T=1, policy="none",
+                    metric="frames/sec, ViT-B/16 temperature-scaled entropy 224x224 global batch=512",
+                    workload="BASELINE configs[4]: ViT-B/16 (MFMA attention path), confidence = 1 - H(softmax(z / 1.5)) / ln C, "
+                             "global batch 512 sharded over the GPUs",
+                    gflop=2 * VIT_B16_GMAC, bound="mfma"),
+    }
 
-    def timed(be, frames, steps, warm=2):
-        for _ in range(warm):
-            be.classify(frames)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            be.classify(frames)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
 
-    u8 = synth.synthetic_frames_u8(256, 224, 224, seed=21)
-    frames = torch.from_numpy(synth.gaussian_noise_f32(u8, 3, seed=3)).cuda()
-    try:
-        be = Backend("resnet50", blob, max_batch=256)
-        dt = timed(be, frames, 10)
-        be.close()
-        out["single_pass"] = {"config": "BASELINE configs[1]: ResNet-50 224x224 batch 256, single pass", "frames_per_s": 256 / dt,
-                              "ms_per_call": dt * 1e3, "tflops": 256 * 2 * RESNET50_GMAC / dt / 1e3}
-    except Exception as e:
-        out["single_pass"] = {"error": str(e)}
-    try:
-        members = [blob] + [weights.make_synthetic("resnet50", seed=s)[0] for s in (2, 3, 4, 5)]
-        be = Backend("resnet50", members, max_batch=32)
-        dt = timed(be, frames[:32], 10)
-        be.close()
-        out["ensemble5@32"] = {"config": "BASELINE configs[3] per-GPU share: 5 x ResNet-50 members, 32 frames per call",
-                               "frames_per_s": 32 / dt, "ms_per_call": dt * 1e3, "tflops": 32 * 5 * 2 * RESNET50_GMAC / dt / 1e3}
-    except Exception as e:
-        out["ensemble5@32"] = {"error": str(e)}
-    try:
+def make_backend(name, c, args, n_max, device, weights, Backend, blob=None):
+    if name == "vit":
         vblob, _ = weights.make_synthetic_vit("vit_b16", seed=1)
-        be = Backend("vit_b16", vblob, max_batch=64, temperature=1.5, conf_kind="entropy")
-        dt = timed(be, frames[:64], 10)
+        return Backend("vit_b16", vblob, device=device, max_batch=n_max, temperature=1.5, conf_kind="entropy")
+    if name == "ens5":
+        members = [blob or weights.make_synthetic("resnet50", seed=1)[0]] + [weights.make_synthetic("resnet50", seed=s)[0] for s in (2, 3, 4, 5)]
+        return Backend("resnet50", members, device=device, max_batch=n_max)
+    if blob is None:
+        blob = weights.make_synthetic("resnet50", seed=1)[0]
+    if c["policy"] == "none":
+        return Backend("resnet50", blob, device=device, max_batch=n_max)
+    return Backend("resnet50", blob, device=device, max_batch=n_max, n_samples=c["T"], dropout_policy=c["policy"],
+                   dropout_p=args.dropout_p, seed=4, chunk_a=args.chunk_a, chunk_b=args.chunk_b, regroup_block=args.regroup_block)
+
+
+def make_frames(n, start, args, torch, synth, device_corrupt=False):
+    """fp32 [0,1] frames with Gaussian noise severity 3, resident on the GPU.  Default: corrupted on the host (NumPy
+    generator, the frames every fixture uses).  --device-corrupt: the clean uint8 frames are uploaded and corrupted by
+    the on-device generator (corrupt.py: Philox noise keyed by the global frame index), before the timed region."""
+    u8 = synth.synthetic_frames_u8(n, 224, 224, seed=21, start_id=start)
+    if device_corrupt:
+        from failure_aware_vision_amd.corrupt import Corruptor
+        return Corruptor(seed=3).gaussian(torch.from_numpy(u8).cuda(), severity=3, first_index=start)
+    return torch.from_numpy(synth.gaussian_noise_f32(u8, 3, seed=3, start_id=start)).cuda()
+
+
+def rooflines(prof, bound):
+    """`roofline` objects of the GEMM-shaped launches (conv / fc / ViT linear + attention: class conv_igemm) from the HIP
+    events recorded on the launch streams around every launch inside the timed region."""
+    cv = prof["conv_igemm"]
+    secs = cv["ms"] * 1e-3
+    total_ms = sum(v["ms"] for v in prof.values())
+    tf = cv["flops"] / secs / 1e12 if secs > 0 else 0.0
+    gbs = cv["bytes"] / secs / 1e9 if secs > 0 else 0.0
+    common = {"kernel": CONV_KERNELS, "launches": cv["launches"], "avg_launch_us": 1e3 * cv["ms"] / max(1, cv["launches"]),
+              "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None,
+              "timing": "HIP events recorded on the launch stream around every launch, inside the timed region"}
+    tr = pmc_traffic()
+    fresh = tr is not None and not tr.get("stale")
+    hbm = dict(common, bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
+               traffic=tr["bytes_per_launch"] if fresh else None,   # HBM bytes per launch from the PMC passes (headline schedule)
+               traffic_detail=tr, algorithmic_bytes_per_launch=cv["bytes"] / max(1, cv["launches"]))
+    mfma = dict(common, bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_BF16_TFLOPS, traffic=None,
+                algorithmic_flop_per_launch=cv["flops"] / max(1, cv["launches"]))
+    return (hbm, mfma) if bound == "hbm" else (mfma, hbm)
+
+
+def measure(be, frames, n_total, rank, world, steps, warmup, torch, dist, classify_sharded, profile=True):
+    def step():
+        return classify_sharded(be, frames, n_total, rank, world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    if profile:
+        be.set_profiling(True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        labels, conf = step()
+        b.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lat_ms = [a.elapsed_time(b) for a, b in ev]
+    prof = be.get_profile() if profile else None
+    be.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, lat_ms, prof, labels
+
+
+def secondary_configs(blob, args, torch, dist, synth, weights, Backend, classify_sharded):
+    """Driver-timed lines for the other BASELINE configs (1 GPU, after the headline's timed region), each with its own
+    `roofline`: configs[1] single pass, configs[3]'s per-GPU share on an 8-GPU node (5 members, 32 frames) and
+    configs[4]'s (ViT-B/16, 64 frames).  fps = frames / wall time of `steps` calls bracketed by synchronize()."""
+    out = {}
+    table = config_table(args)
+    frames = make_frames(256, 0, args, torch, synth)
+    for key, name, n in (("single_pass", "single", 256), ("ensemble5@32", "ens5", 32), ("vit_b16@64", "vit", 64)):
+        c = table[name]
+        try:
+            be = make_backend(name, c, args, n, torch.cuda.current_device(), weights, Backend, blob)
+            elapsed, lat, prof, _ = measure(be, frames[:n], n, 0, 1, 10, 2, torch, dist, classify_sharded)
+            be.close()
+            dt = elapsed / 10
+            primary, other = rooflines(prof, c["bound"])
+            out[key] = {"config": c["workload"] + (" - per-GPU share of an 8-GPU node: %d frames per call" % n if c["scaling"] == "strong" else ""),
+                        "frames_per_s": n / dt, "ms_per_call": dt * 1e3, "tflops": n * c["gflop"] / dt / 1e3,
+                        "roofline": primary, "roofline_" + other["bound"]: other}
+        except Exception as e:
+            out[key] = {"error": str(e)}
+    return out
+
+
+def seam_latency(blob, torch, synth, Backend):
+    """The reference's own operating point (main.py:122,160,205; video_source.py:29-30): ONE 320x240 uint8 frame per call
+    through Backend.analyze_frame (upload, rule statistics kernel, classifier, one host sync, scalar scoring), 200 calls,
+    for the headline estimator (T = 30) and a single pass, against the 33.3 ms tick of the 30 Hz loop."""
+    out = {"budget_ms": 1000.0 / 30.0, "frame": "320x240x3 uint8 (host)", "calls": 200,
+           "path": "Backend.analyze_frame: one upload, signal_stats_kernel + ResNet-50, one sync, dict as signal_analyzer.py:128-143"}
+    frames = synth.synthetic_frames_u8(8, 240, 320, seed=5)
+    for key, kw in (("mc30", dict(n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)), ("single_pass", {})):
+        be = Backend("resnet50", blob, in_hw=(240, 320), max_batch=1, **kw)
+        for i in range(10):
+            be.analyze_frame(frames[i % 8])
+        lat = []
+        for i in range(200):
+            t0 = time.perf_counter()
+            r = be.analyze_frame(frames[i % 8])
+            lat.append((time.perf_counter() - t0) * 1e3)
         be.close()
-        out["vit_b16@64"] = {"config": "BASELINE configs[4] per-GPU share: ViT-B/16, 64 frames per call, entropy confidence",
-                             "frames_per_s": 64 / dt, "ms_per_call": dt * 1e3, "tflops": 64 * 2 * VIT_B16_GMAC / dt / 1e3}
-    except Exception as e:
-        out["vit_b16@64"] = {"error": str(e)}
+        lat.sort()
+        out[key] = {"p50_ms": lat[100], "p95_ms": lat[190], "max_ms": lat[-1], "last_status": r["vision_status"]}
     return out
 
 
@@ -204,28 +357,34 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--config", default=None, choices=["mc30", "single", "ens5", "vit"],
+                    help="the BASELINE config to measure (default: the headline, configs[2], with the others under `extra`)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (mc30, single)")
     ap.add_argument("--samples", type=int, default=30, help="MC-Dropout T")
     ap.add_argument("--policy", default="all_blocks", choices=["none", "last_layer", "layer4+fc", "all_blocks"])
     ap.add_argument("--dropout-p", type=float, default=0.1)
     ap.add_argument("--chunk-a", type=int, default=0)
     ap.add_argument("--chunk-b", type=int, default=0)
     ap.add_argument("--regroup-block", type=int, default=-1)
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-repeats", type=int, default=3, help="timed repeats of the CPU baseline")
+    ap.add_argument("--device-corrupt", action="store_true", help="corrupt the frames with the on-device generator (corrupt.py)")
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-repeats", type=int, default=2, help="timed repeats of the CPU baseline")
+    ap.add_argument("--cpu-port-frames", type=int, default=4, help="frames of the oracle-port CPU figure (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = the CPUs this job may use)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs (single pass, ensemble, ViT)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs and the seam latency")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args(argv)
 
 
 def main():
     args = parse_args()
+    # dmabuf IPC: what RCCL needs on this host driver; set before anything loads the HIP runtime, also when the ranks
+    # were started directly by torchrun
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # ---- rank layout; self-launch BEFORE anything initialises the GPU -------------------------
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             env = dict(os.environ)
-            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
             env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
             sys.exit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
         world, rank, local_rank = 1, 0, 0
@@ -239,110 +398,74 @@ def main():
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
-    from failure_aware_vision_amd import Backend, classify_sharded, synth, weights
+    from failure_aware_vision_amd import Backend, classify_sharded, shard_range, synth, weights
 
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    T = args.samples if args.policy != "none" else 1
+    name = args.config or "mc30"
+    c = config_table(args)[name]
+    if c["scaling"] == "weak":
+        n_total = c["per_gpu"] * world
+    else:
+        n_total = c["global_batch"]
+    start, stop = shard_range(n_total, rank, world)
+    n_local = stop - start
     blob, info = weights.make_synthetic("resnet50", seed=1)
-    be = Backend("resnet50", blob, device=local_rank, max_batch=args.batch, n_samples=T, dropout_policy=args.policy,
-                 dropout_p=args.dropout_p if args.policy != "none" else 0.0, seed=4,
-                 chunk_a=args.chunk_a, chunk_b=args.chunk_b, regroup_block=args.regroup_block)
-    n_total = args.batch * world
-    start = rank * args.batch
-    frames_u8 = synth.synthetic_frames_u8(args.batch, 224, 224, seed=21, start_id=start)
-    frames = torch.from_numpy(synth.gaussian_noise_f32(frames_u8, 3, seed=3, start_id=start)).cuda()
+    be = make_backend(name, c, args, max(1, -(-n_total // world)), local_rank, weights, Backend, blob)
+    frames = make_frames(n_local, start, args, torch, synth, args.device_corrupt)
+    T = c["T"]
 
-    def step():
-        return classify_sharded(be.classify, frames, n_total, rank, world)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    profile = not args.no_profile
-    if profile:
-        be.set_profiling(True)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        labels, conf = step()
-        b.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lat_ms = [a.elapsed_time(b) for a, b in ev]
-    prof = be.get_profile() if profile else None
-    be.set_profiling(False)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, lat_ms, prof, labels = measure(be, frames, n_total, rank, world, args.steps, args.warmup, torch, dist,
+                                            classify_sharded, profile=not args.no_profile)
 
     out = None
     if rank == 0:
         fps = n_total * args.steps / elapsed
-        gf = algorithmic_gflop_per_frame(args.policy, T)
+        gf = c["gflop"]
         out = {
-            "metric": "frames/sec, ResNet-50 MC-Dropout T=%d 224x224 batch=%d" % (T, args.batch),
+            "metric": c["metric"],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": c["scaling"],
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "p50_latency_ms": statistics.median(lat_ms),
-            "config": {"workload": "BASELINE configs[2]: ResNet-50 v1.5 + MC-Dropout T=%d (%s, p=%.2f), 224x224x3 fp32 "
-                                   "frames with Gaussian noise severity 3, batch %d per GPU, synthetic frames and "
-                                   "seeded synthetic weights" % (T, args.policy, args.dropout_p, args.batch),
-                       "frames_per_gpu": args.batch, "global_batch": n_total, "mc_samples": T,
-                       "dropout_policy": args.policy, "algorithmic_gflop_per_frame": gf,
-                       "inputs": "resident in HBM before the timed region (H2D excluded)",
+            "config": {"workload": c["workload"],
+                       "frames_per_gpu": n_local, "global_batch": n_total, "mc_samples": T,
+                       "dropout_policy": c["policy"], "algorithmic_gflop_per_frame": gf,
+                       "inputs": "resident in HBM before the timed region (H2D excluded)" +
+                                 ("; corrupted by the on-device generator" if args.device_corrupt else ""),
                        "parallelism": "batch sharded, 1 process per GPU, all-gather of (label, confidence)"},
             "achieved_tflops_algorithmic": fps * gf / 1000.0 / world,
             "labels_distinct": int(len(set(labels.cpu().tolist()))),
         }
         if prof is not None:
-            cv = prof["conv_igemm"]
-            secs = cv["ms"] * 1e-3
-            total_ms = sum(v["ms"] for v in prof.values())
-            tf = cv["flops"] / secs / 1e12 if secs > 0 else 0.0
-            gbs = cv["bytes"] / secs / 1e9 if secs > 0 else 0.0
-            common = {"kernel": "fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel + fav::entry_reduce_kernel "
-                                "(every conv / fc launch of the timed steps)",
-                      "launches": cv["launches"], "avg_launch_us": 1e3 * cv["ms"] / max(1, cv["launches"]),
-                      "share_of_kernel_time": cv["ms"] / total_ms if total_ms > 0 else None,
-                      "timing": "HIP events recorded on the launch stream around every launch, inside the timed region"}
-            # Layer by layer the workload is HBM-bound overall (algorithmic FLOP/B below the machine
-            # balance of 312 FLOP/B), so the binding roofline is HBM.
-            tr = pmc_traffic()
-            fresh = tr is not None and not tr.get("stale")
-            out["roofline"] = dict(common, bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
-                                   frac=gbs / PEAK_HBM_GBS,
-                                   traffic=tr["bytes_per_launch"] if fresh else None,   # HBM bytes per launch from the PMC passes
-                                   traffic_detail=tr,
-                                   algorithmic_bytes_per_launch=cv["bytes"] / max(1, cv["launches"]))
-            out["roofline_mfma"] = dict(common, bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                                        frac=tf / PEAK_BF16_TFLOPS, traffic=None)
+            primary, other = rooflines(prof, c["bound"])
+            out["roofline"] = primary
+            out["roofline_" + other["bound"]] = other
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
     be.close()
     if rank == 0:
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and args.config is None:
             try:
-                out["extra"] = secondary_configs(blob, args, torch, synth, weights, Backend)
+                out["extra"] = secondary_configs(blob, args, torch, dist, synth, weights, Backend, classify_sharded)
             except Exception as e:   # secondary lines are reported, never required
                 out["extra"] = {"error": str(e)}
-        if args.cpu_frames > 0 and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             try:
-                out["cpu_baseline"] = cpu_baseline(blob, args, T, args.policy)
+                out["extra"]["seam_320x240"] = seam_latency(blob, torch, synth, Backend)
+            except Exception as e:
+                out["extra"]["seam_320x240"] = {"error": str(e)}
+        if args.cpu_frames > 0 and world == 1 and name == "mc30":   # the CPU baseline is timed on rank 0 of the 1-GPU run only
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, T, c["policy"])
                 out["gpu_over_cpu"] = fps / world / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            if args.cpu_port_frames > 0:
+                try:
+                    out["cpu_baseline_oracle_port"] = cpu_baseline_oracle_port(blob, args, T, c["policy"])
+                except Exception as e:
+                    out["cpu_baseline_oracle_port"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

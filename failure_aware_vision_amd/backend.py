@@ -153,6 +153,26 @@ class Backend:
                                             conf.data_ptr(), fail.data_ptr(), score.data_ptr(), stream), self._h)
         return labels, conf, fail, score
 
+    def classify_records(self, images, first_index: int = 0, out=None):
+        """frames (CUDA tensor) -> int32[n, 2] CUDA tensor of packed (label, confidence bits) records, written by the
+        confidence head itself (fav_classify_records).  ``out``: a contiguous int32[n, 2] view to write into - e.g. this
+        rank's slot of an all-gather send buffer (distributed.classify_sharded), so nothing is packed or copied."""
+        torch = self._torch
+        self._check_shape(images)
+        layout = self._layout_of(images)
+        n = int(images.shape[0])
+        if isinstance(images, np.ndarray) or not images.is_cuda or images.device.index != self.device:
+            raise ValueError(f"classify_records takes frames on cuda:{self.device}")
+        img = images.contiguous()
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.int32, device=img.device)
+        if out.dtype != torch.int32 or tuple(out.shape) != (n, 2) or not out.is_contiguous() or out.device != img.device:
+            raise ValueError("out must be a contiguous int32[n, 2] tensor on the frames' device")
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        _lib.check(self.lib.fav_classify_records(self._h, img.data_ptr(), n, layout, int(first_index), out.data_ptr(),
+                                                 None, None, stream), self._h)
+        return out
+
     def classify(self, images, first_index: int = 0):
         """The drop-in: frames -> (labels, confidences)."""
         labels, conf, _, _ = self.classify_detect(images, first_index)

@@ -733,7 +733,7 @@ const char* launch_entry_reduce(fav_handle* h, const void* x, void* y, const voi
 }
 
 const char* launch_head(fav_handle* h, const float* logits, int T, int n, int C, int ld, float temperature, int kind,
-                        float tau, int* labels, float* conf, uint8_t* fail, float* score, hipStream_t s) {
+                        float tau, int* labels, float* conf, uint8_t* fail, float* score, hipStream_t s, int out_stride = 1) {
     if (C > 1024 || C < 1) return "head: num_classes must be in [1, 1024]";
     if (ld % 4 != 0 || ld < C) return "head: bad row stride";
     const float inv_temp = 1.0f / temperature;
@@ -741,10 +741,10 @@ const char* launch_head(fav_handle* h, const float* logits, int T, int n, int C,
     Prof pr(h, s, FAV_K_HEAD, 0.0, 4.0 * (double)T * n * C + 8.0 * n);
     if (C <= 256)
         hipLaunchKernelGGL((head_kernel<1>), dim3(n), dim3(256), 0, s, logits, T, n, C, ld, inv_temp, kind, tau, inv_lnC,
-                           labels, conf, fail, score);
+                           labels, conf, fail, score, out_stride);
     else
         hipLaunchKernelGGL((head_kernel<4>), dim3(n), dim3(256), 0, s, logits, T, n, C, ld, inv_temp, kind, tau, inv_lnC,
-                           labels, conf, fail, score);
+                           labels, conf, fail, score, out_stride);
     return nullptr;
 }
 
@@ -1622,7 +1622,7 @@ void mark_last_use(fav_handle* h, hipStream_t s) {
     if (h->ev_last && hipEventRecord(h->ev_last, s) == hipSuccess) h->ev_last_set = true;
 }
 fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
-                              int32_t* labels, float* conf, uint8_t* fail, float* score, hipStream_t s);
+                              int32_t* labels, float* conf, uint8_t* fail, float* score, hipStream_t s, int out_stride);
 }  // namespace
 
 fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
@@ -1636,21 +1636,37 @@ fav_status fav_classify_ex(fav_handle* h, const void* images, int32_t n, int32_t
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (fav_status st = wait_last_use(h, s)) return st;
-    const fav_status st = classify_on_stream(h, images, n, layout, first_index, labels, conf, fail, score, s);
+    const fav_status st = classify_on_stream(h, images, n, layout, first_index, labels, conf, fail, score, s, 1);
     mark_last_use(h, s);      // also after a failure: whatever was queued before it still uses the buffers
+    return st;
+}
+
+fav_status fav_classify_records(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
+                                void* records, uint8_t* fail, float* score, void* stream) {
+    if (!h) return FAV_ERR_INVALID_ARG;
+    if (!h->weights_loaded) { h->err = "fav_classify_records: no weights loaded"; return FAV_ERR_NO_WEIGHTS; }
+    if (!images || !records || ((uintptr_t)records & 7)) { h->err = "fav_classify_records: null or misaligned buffer"; return FAV_ERR_INVALID_ARG; }
+    if (n < 1 || n > h->cfg.max_batch) { h->err = fmt("fav_classify_records: n=%d outside [1, max_batch=%d]", n, h->cfg.max_batch); return FAV_ERR_INVALID_ARG; }
+    if (layout != FAV_LAYOUT_NHWC_U8 && layout != FAV_LAYOUT_NHWC_F32) { h->err = "fav_classify_records: unknown layout"; return FAV_ERR_INVALID_ARG; }
+    if (first_index < 0 || first_index + n > 0xFFFFFFFFll) { h->err = "fav_classify_records: first_image_index out of range"; return FAV_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (fav_status st = wait_last_use(h, s)) return st;
+    const fav_status st = classify_on_stream(h, images, n, layout, first_index, (int32_t*)records, (float*)records + 1, fail, score, s, 2);
+    mark_last_use(h, s);
     return st;
 }
 
 namespace {
 fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int32_t layout, int64_t first_index,
-                              int32_t* labels, float* conf, uint8_t* fail, float* score, hipStream_t s) {
+                              int32_t* labels, float* conf, uint8_t* fail, float* score, hipStream_t s, int out_stride) {
     h->ev_used = h->profiling ? h->ev_used : 0;
     if (h->vit) {
         for (auto& L : h->layers) { L.w = L.w_m[0]; L.b = L.b_m[0]; }
         // the batch in FAV_VIT_STREAMS (default 2) parts on as many streams: at 197 rows per frame every GEMM of the encoder is a
         // few hundred tiles, and the partial last round of one part's launch is filled by another part's (1: one stream)
         static const int vit_streams = [] { const char* e = getenv("FAV_VIT_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-        if (vit_streams > 1 && n >= 8 * vit_streams && !h->profiling) {
+        if (vit_streams > 1 && n >= 8 * vit_streams) {
             if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             while ((int)h->vit_streams.size() < vit_streams) {
                 hipStream_t st_; hipEvent_t ev_;
@@ -1734,7 +1750,7 @@ fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int3
     if (!h->vit) h->phase_out.back() = h->logits;
     const int T_head = h->n_members > 1 ? h->n_members : h->T_eff;
     if (const char* e = launch_head(h, h->logits, T_head, n, h->cfg.num_classes, h->cpad, h->cfg.temperature,
-                                    h->cfg.conf_kind, h->cfg.tau, labels, conf, fail, score, s)) {
+                                    h->cfg.conf_kind, h->cfg.tau, labels, conf, fail, score, s, out_stride)) {
         h->err = e;
         return FAV_ERR_INVALID_ARG;
     }

@@ -2305,7 +2305,9 @@ template <int NV>  // float4 groups per lane: supports num_classes <= 256 * NV
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ logits, int T, int n, int C, int ld,
                                                    float inv_temp, int conf_kind, float tau, float inv_lnC,
                                                    int* __restrict__ labels, float* __restrict__ conf,
-                                                   uint8_t* __restrict__ fail, float* __restrict__ score) {
+                                                   uint8_t* __restrict__ fail, float* __restrict__ score, int out_stride) {
+    // out_stride: element pitch of labels / conf (1: two arrays; 2: one packed (label, confidence) record per frame,
+    // labels = record base, conf = record base + 1 - the 8-byte unit the multi-GPU all-gather moves)
     __shared__ __attribute__((aligned(16))) float part[4][NV * 256];
     __shared__ float red_v[4];
     __shared__ int red_i[4];
@@ -2393,8 +2395,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ log
             hh += red_h[w];
         }
         const float cf = conf_kind == 0 ? bv : 1.0f - hh * inv_lnC;
-        labels[img] = bi;
-        conf[img] = cf;
+        labels[(long long)img * out_stride] = bi;
+        conf[(long long)img * out_stride] = cf;
         if (fail) fail[img] = cf < tau ? 1 : 0;
         if (score) score[img] = fminf(fmaxf(1.0f - cf, 0.f), 1.f);
     }

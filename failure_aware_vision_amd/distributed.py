@@ -31,34 +31,47 @@ def unpack_records(rec):
     return rec[:, 0].contiguous(), rec[:, 1].contiguous().view(torch.float32)
 
 
-def classify_sharded(classify_fn, local_frames, n_total: int, rank: int, world: int, group=None):
-    """Each rank calls ``classify_fn(local_frames, first_index=start)`` on its own shard
-    and all ranks receive the full (labels[n_total], conf[n_total]).
+def classify_sharded(classifier, local_frames, n_total: int, rank: int, world: int, group=None):
+    """Each rank classifies its own shard (global frame indices [start, stop)) and all ranks receive the full
+    (labels[n_total], conf[n_total]).
 
-    ``classify_fn`` is ``Backend.classify`` on a GPU rank; results are gathered on the
-    device they live on (RCCL for CUDA tensors, gloo for CPU tensors)."""
+    ``classifier`` is a ``Backend`` on a GPU rank: its confidence head writes the packed 8-byte records straight into
+    this rank's slot of the all-gather send buffer (``Backend.classify_records``), one ``all_gather_into_tensor``
+    (RCCL) moves them, and the results are views of the receive buffer - no pack, pad or concatenate launches.
+    A plain function ``classify_fn(frames, first_index=...) -> (labels, conf)`` is accepted too (CPU tensors / gloo:
+    the tests that stand the oracle in for the per-rank classifier)."""
     import torch
     import torch.distributed as dist
     start, stop = shard_range(n_total, rank, world)
     n_local = stop - start
-    if n_local > 0:
-        if int(local_frames.shape[0]) != n_local:
-            raise ValueError(f"rank {rank} owns frames [{start},{stop}) but was handed {int(local_frames.shape[0])}")
-        labels, conf = classify_fn(local_frames, first_index=start)
-        if isinstance(labels, np.ndarray):
-            labels, conf = torch.from_numpy(labels), torch.from_numpy(conf)
-        rec = pack_records(labels, conf)
-        dev = rec.device
-    else:
-        dev = local_frames.device if hasattr(local_frames, "device") and not isinstance(local_frames, np.ndarray) else "cpu"
-        rec = torch.zeros((0, 2), dtype=torch.int32, device=dev)
-    if world == 1:
-        return unpack_records(rec)
+    if n_local > 0 and int(local_frames.shape[0]) != n_local:
+        raise ValueError(f"rank {rank} owns frames [{start},{stop}) but was handed {int(local_frames.shape[0])}")
     cap = -(-n_total // world)  # every shard padded to the largest
-    send = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
-    send[:n_local] = rec
+    direct = hasattr(classifier, "classify_records")
+    if direct:
+        dev = local_frames.device
+        send = torch.empty((cap, 2), dtype=torch.int32, device=dev) if n_local == cap else \
+            torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+        if n_local > 0:
+            classifier.classify_records(local_frames, first_index=start, out=send[:n_local])
+    else:
+        if n_local > 0:
+            labels, conf = classifier(local_frames, first_index=start)
+            if isinstance(labels, np.ndarray):
+                labels, conf = torch.from_numpy(labels), torch.from_numpy(conf)
+            rec = pack_records(labels, conf)
+            dev = rec.device
+        else:
+            dev = local_frames.device if hasattr(local_frames, "device") and not isinstance(local_frames, np.ndarray) else "cpu"
+            rec = torch.zeros((0, 2), dtype=torch.int32, device=dev)
+        send = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+        send[:n_local] = rec
+    if world == 1:
+        return unpack_records(send[:n_local]) if not direct else (send[:n_local, 0], send[:n_local, 1].view(torch.float32))
     recv = torch.empty((world * cap, 2), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
+    if n_total == world * cap:                 # equal shards: the receive buffer IS the result
+        return recv[:, 0], recv[:, 1].view(torch.float32)
     parts = []
     for r in range(world):
         s, e = shard_range(n_total, r, world)

@@ -119,6 +119,15 @@ fav_status fav_classify_ex(fav_handle* h, const void* images_dev, int32_t n, int
                            int64_t first_image_index, int32_t* labels_dev, float* conf_dev,
                            uint8_t* fail_dev, float* score_dev, void* hip_stream);
 
+/* Same as fav_classify_ex with the two result arrays packed: records_dev[n] holds one 8-byte record per frame,
+ * { int32 label, fp32 confidence } (8-byte aligned device pointer).  This is the unit the multi-GPU path exchanges
+ * (one all-gather of 8 B per frame): the confidence head writes each rank's records straight
+ * into its slot of the all-gather send buffer, no pack / concatenate launches in between.  The reference is a
+ * single process and has no counterpart ("Distributed communication backend: None"). */
+fav_status fav_classify_records(fav_handle* h, const void* images_dev, int32_t n, int32_t layout,
+                                int64_t first_image_index, void* records_dev, uint8_t* fail_dev,
+                                float* score_dev, void* hip_stream);
+
 /* Host-buffer convenience (frames and results in host memory; synchronous). */
 fav_status fav_classify_host(fav_handle* h, const void* images_host, int32_t n, int32_t layout,
                              int64_t first_image_index, int32_t* labels_host, float* conf_host,

@@ -191,17 +191,25 @@ def _im2col(x: np.ndarray, kh: int, kw: int, stride: int, pad: int):
 _EXACT_LIB = None
 
 
-def _exact_lib():
-    """oracle/_build/libfav_exact.so: the accumulator in the HIP kernel's exact-mode order."""
+def _exact_lib(optional=False):
+    """oracle/_build/libfav_exact.so: the accumulator in the HIP kernel's exact-mode order.  optional=True: None
+    instead of a build attempt when the library is absent (callers then use their NumPy form)."""
     global _EXACT_LIB
     if _EXACT_LIB is None:
         import ctypes
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libfav_exact.so")
         if not os.path.exists(path):
+            if optional:
+                return None
             import subprocess
             subprocess.check_call(["make", "-C", os.path.dirname(os.path.abspath(__file__))])
         lib = ctypes.CDLL(path)
+        lib.fav_epilogue_bf16.restype = None
+        lib.fav_epilogue_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_long,
+                                          ctypes.c_int]
+        lib.fav_bf16mfma_conv_acc_order.restype = ctypes.c_int
+        lib.fav_bf16mfma_conv_acc_order.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 9 + [ctypes.c_void_p]
         for fn in (lib.fav_exact_conv_acc, lib.fav_bf16mfma_conv_acc):
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 9
@@ -259,6 +267,26 @@ def conv_acc(x: np.ndarray, L: ConvLayer, exact: bool = False) -> np.ndarray:
 
 
 def epilogue(acc, bias, res=None, relu=True, keep=None, scale=np.float32(1.0)) -> np.ndarray:
+    """((acc + bias) + residual), ReLU, dropout, one rounding to bf16.  `epilogue_numpy` is the specification; the C
+    restatement (fav_exact.c: fav_epilogue_bf16, the same fp32 operations in the same order, multithreaded) is used when
+    the library is built - tests/test_oracle.py compares the two."""
+    lib = _exact_lib(optional=True)
+    if lib is None:
+        return epilogue_numpy(acc, bias, res, relu, keep, scale)
+    acc = np.ascontiguousarray(acc, np.float32)
+    b32 = np.ascontiguousarray(bias, np.float32)
+    c = acc.shape[-1]
+    assert b32.shape == (c,)
+    r32 = None if res is None else np.ascontiguousarray(np.broadcast_to(res, acc.shape), np.float32)
+    k8 = None if keep is None else np.ascontiguousarray(np.asarray(keep).reshape(acc.shape), np.uint8)
+    out = np.empty_like(acc)
+    lib.fav_epilogue_bf16(acc.ctypes.data, b32.ctypes.data, None if r32 is None else r32.ctypes.data,
+                          None if k8 is None else k8.ctypes.data, float(scale), 1 if relu else 0, out.ctypes.data,
+                          acc.size // c, c)
+    return out
+
+
+def epilogue_numpy(acc, bias, res=None, relu=True, keep=None, scale=np.float32(1.0)) -> np.ndarray:
     y = acc + bias.astype(np.float32)
     if res is not None:
         y = y + res

@@ -48,3 +48,34 @@ def test_gaussian_noise_matches_restatement_and_has_the_right_sigma():
     mid = (frames > 60) & (frames < 195)                        # unclipped pixels
     resid = (out - frames.astype(np.float32) / 255.0)[mid]
     assert abs(resid.std() - 0.18) < 0.005 and abs(resid.mean()) < 0.002
+
+
+def test_device_corruption_feeds_the_classifier(r50_blob):
+    """SURVEY.md section 8f row 3, wired in: clean uint8 frames -> Gaussian noise severity 3 ON THE DEVICE
+    (Corruptor.gaussian, vision_simulator.py:15 / app.js:789-857 are the reference's modes) -> classify, against the same
+    frames corrupted on the host by the generator's CPU restatement (identical Philox draws; pixels within 2e-6 through
+    logf / sqrtf / cosf) -> classify.  A 2e-6 pixel difference is far below one bf16 ulp of a normalised pixel, so almost
+    every input element rounds to the same bf16: labels equal except where the top-2 gap is tiny, confidences close."""
+    from failure_aware_vision_amd import Backend
+    blob, _ = r50_blob
+    n = 128
+    u8 = synth.synthetic_frames_u8(n, 224, 224, seed=21)
+    c = Corruptor(seed=3)
+    dev = c.gaussian(torch.from_numpy(u8).cuda(), severity=3, first_index=0)
+    host = np.concatenate([CO.corrupt(u8[s:s + 16], 3, 0, 1, 0.18, 3, s) for s in range(0, n, 16)])
+    assert np.abs(dev.cpu().numpy() - host).max() < 2e-6
+    for kw in (dict(), dict(n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)):
+        be = Backend("resnet50", blob, max_batch=n, **kw)
+        ld, cd = be.classify(dev)
+        lh, ch = be.classify(torch.from_numpy(host).cuda())
+        pd = torch.softmax(be.logits(), dim=-1).mean(dim=0)
+        top2 = torch.topk(pd, 2, dim=-1).values
+        gap = (top2[:, 0] - top2[:, 1]).cpu().numpy()
+        bad = (ld != lh).cpu().numpy()
+        dconf = (cd - ch).abs().max().item()
+        print(f"device-corrupted vs host-corrupted frames ({'T=30' if kw else 'single pass'}): {n - bad.sum()} / {n} labels equal, "
+              f"largest gap among the others {gap[bad].max() if bad.any() else 0:.4f}, max |dconf| {dconf:.5f}")
+        assert bad.sum() <= 2 and np.all(gap[bad] < 0.01)
+        assert dconf < 0.01
+        assert len(set(ld.cpu().tolist())) > 10
+        be.close()

@@ -165,7 +165,7 @@ def test_full_size_properties(r50_blob):
     la, ca = be.classify(frames[:128], first_index=0)
     lb, cb = be.classify(frames[128:], first_index=128)
     assert torch.equal(torch.cat([la, lb]), l0) and torch.equal(torch.cat([ca, cb]), c0)
-    assert len(set(l0.cpu().tolist())) >= 5          # not a degenerate model (mean over 30 samples on clean frames)
+    assert len(set(l0.cpu().tolist())) > 20          # not a degenerate model (mean over 30 samples on clean frames)
     assert lg0.shape == (T, n, 1000) and torch.isfinite(lg0).all()
     assert not torch.equal(lg0[0], lg0[1])            # samples really differ
     be.close()
@@ -267,3 +267,83 @@ def test_one_call_scorer_at_the_seam(r50_blob):
     assert after[0] is before[0] and after[1:] == before[1:]
     eng.update(bad["vision_status"], bad["anomaly_score"], 1 / 30)
     be.close(); ref_be.close()
+
+
+def test_records_entry_and_calls_on_different_streams(r18_blob):
+    """fav_classify_records: the head writes packed (label, confidence) records - the unit the multi-GPU all-gather moves.
+    And the handle orders calls issued on DIFFERENT streams on the device (ev_last): a host-buffer classify (the handle's
+    own stream) or a call on a second torch stream, issued while a call on the first stream is still running, neither
+    corrupts that call's result nor reads its activations half written."""
+    from failure_aware_vision_amd import classify_sharded
+    blob, _ = r18_blob
+    n = 64
+    frames_np = synth.synthetic_frames_u8(n, 32, 32, seed=13)
+    frames = torch.from_numpy(frames_np).cuda()
+    kw = dict(n_samples=8, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    be = Backend("resnet18_cifar", blob, max_batch=n, **kw)
+    l0, c0 = be.classify(frames)
+    rec = be.classify_records(frames)
+    assert rec.dtype == torch.int32 and tuple(rec.shape) == (n, 2)
+    assert torch.equal(rec[:, 0], l0) and torch.equal(rec[:, 1].contiguous().view(torch.float32), c0)
+    slot = torch.full((n + 4, 2), -7, dtype=torch.int32, device="cuda")            # a slot inside a larger send buffer
+    be.classify_records(frames[:10], first_index=0, out=slot[2:12])
+    assert torch.equal(slot[2:12, 0], l0[:10]) and int((slot[:2] != -7).sum()) == 0 and int((slot[12:] != -7).sum()) == 0
+    ls, cs = classify_sharded(be, frames, n, 0, 1)                                  # world 1: views of the send buffer
+    assert torch.equal(ls, l0) and torch.equal(cs, c0)
+    with pytest.raises(ValueError):
+        be.classify_records(frames, out=torch.empty((n, 2), dtype=torch.int64, device="cuda"))
+    # two streams, no host synchronisation in between
+    half = frames_np[:32]
+    lh_ref, ch_ref = be.classify(half)
+    lh_ref, ch_ref = lh_ref.cpu().numpy(), ch_ref.cpu().numpy()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(5):
+        la, ca = be.classify(frames)                          # current stream, asynchronous
+        lb, cb = be.classify(half)                            # numpy in: the handle's own stream, synchronous
+        with torch.cuda.stream(side):
+            lc, cc = be.classify(frames)                      # a second torch stream
+        torch.cuda.synchronize()
+        assert np.array_equal(lb, lh_ref) and np.array_equal(cb, ch_ref)
+        assert torch.equal(la, l0) and torch.equal(ca, c0) and torch.equal(lc, l0) and torch.equal(cc, c0)
+    be.close()
+
+
+def test_full_size_properties_vit_and_ensemble(r50_members):
+    """The two 8-GPU configs of BASELINE.json at their real sizes, production mode, no oracle: determinism, shard
+    invariance (what the multi-GPU path relies on) and neighbour independence.  configs[4]: ViT-B/16 at its global batch
+    512 and at the per-GPU share 64 (32 + 32 shards; the two-stream split inside a call is on); configs[3]: the 5-member
+    ensemble at its global batch 256 (128 + 128 and a ragged 100 + 156 split)."""
+    vblob, _ = weights.make_synthetic_vit("vit_b16", seed=1)
+    x = torch.from_numpy(synth.synthetic_frames_u8(512, 224, 224, seed=21)).cuda()
+    vit = Backend("vit_b16", vblob, max_batch=512, temperature=1.5, conf_kind="entropy")
+    l0, c0 = vit.classify(x)
+    lg0 = vit.logits()
+    l1, c1 = vit.classify(x)
+    assert torch.equal(l0, l1) and torch.equal(c0, c1) and torch.isfinite(lg0).all()
+    for cut in (256, 200):
+        la, ca = vit.classify(x[:cut], first_index=0)
+        lb, cb = vit.classify(x[cut:], first_index=cut)
+        assert torch.equal(torch.cat([la, lb]), l0) and torch.equal(torch.cat([ca, cb]), c0), cut
+    la, ca = vit.classify(x[:64])
+    lb, cb = vit.classify(x[:32]); lc, cc = vit.classify(x[32:64])
+    assert torch.equal(la, l0[:64]) and torch.equal(torch.cat([lb, lc]), la) and torch.equal(torch.cat([cb, cc]), ca)
+    perm = torch.randperm(512, generator=torch.Generator().manual_seed(1)).cuda()
+    lp, cp = vit.classify(x[perm])
+    assert torch.equal(lp, l0[perm]) and torch.equal(cp, c0[perm])
+    assert len(set(l0.cpu().tolist())) > 20
+    vit.close()
+    ens = Backend("resnet50", [b for b, _ in r50_members], max_batch=256)
+    x = x[:256]
+    l0, c0 = ens.classify(x)
+    l1, c1 = ens.classify(x)
+    assert torch.equal(l0, l1) and torch.equal(c0, c1)
+    for cut in (128, 100):
+        la, ca = ens.classify(x[:cut], first_index=0)
+        lb, cb = ens.classify(x[cut:], first_index=cut)
+        assert torch.equal(torch.cat([la, lb]), l0) and torch.equal(torch.cat([ca, cb]), c0), cut
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(2)).cuda()
+    lp, cp = ens.classify(x[perm])
+    assert torch.equal(lp, l0[perm]) and torch.equal(cp, c0[perm])
+    assert len(set(l0.cpu().tolist())) > 20
+    ens.close()

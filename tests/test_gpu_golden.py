@@ -9,7 +9,9 @@ expected labels / confidences computed once by the CPU oracle in exact mode
   the test states the measured agreement and bounds every disagreement by that gap.
 * bf16 production mode against its OWN fixtures (oracle with the bit-exact model of
   v_mfma_f32_16x16x32_bf16, `exact="mfma"`): every logit bit-identical (per-frame CRC-32 of
-  the fp32 logits), labels exactly equal, confidences within 3e-6.
+  the fp32 logits), labels exactly equal, confidences within 3e-6 - on all 10,000 frames.
+* bf16 production mode against two oracles that know nothing of the MFMA adder: oracle/torch_cpu.py
+  (10,000 frames) and the pure fp32 nn.Module of oracle/torch_fp32.py (1,000 frames).
 """
 import os
 import zlib
@@ -71,53 +73,6 @@ def test_production_mode_mc_dropout_t30_fixture(r50_blob, monkeypatch, min_rows)
     be.close()
 
 
-def test_production_mode_thousand_corrupted_frames(r50_blob):
-    """1,000 corrupted frames, single pass, PRODUCTION bf16 mode: bit-identical logits."""
-    blob, info = r50_blob
-    d = load("r50_mfma_1k_noise3.npz", info)
-    n, bs = len(d["labels"]), 250
-    be = Backend("resnet50", blob, max_batch=bs)
-    for s in range(0, n, bs):
-        labels, conf = be.classify(frames(s, bs))
-        assert np.array_equal(frame_crc(be.logits()), d["logit_crc32"][s:s + bs]), s
-        tie = d["gap"][s:s + bs] < 1e-6
-        assert np.array_equal(labels.cpu().numpy()[~tie], d["labels"][s:s + bs].astype(np.int32)[~tie])
-        np.testing.assert_allclose(conf.cpu().numpy(), d["conf"][s:s + bs], rtol=0, atol=3e-6)
-    be.close()
-
-
-def test_production_mode_vs_independent_torch_cpu(r50_blob):
-    """Independent evidence for the production mode: labels and confidences of 1,000 corrupted
-    frames against oracle/torch_cpu.py - torch.nn.functional fp32 CPU convolutions in the library's own summation
-    order, bf16 layer boundaries; generated in the build container by tests/golden/make_torchcpu_fixture.py.  That
-    oracle knows nothing about the MFMA adder, so nothing here is "bit-exact versus a model fitted to the GPU".
-    Measured when the fixture was made (production-mode fixture == GPU output bit for bit): 980 / 1000 labels equal,
-    every one of the 20 others on a frame whose top-2 probability gap (torch's own) is below 0.0097 and 19 of them
-    torch's second choice; max |confidence difference| 0.0231.  The bounds below leave ~1.5-2x margin."""
-    blob, info = r50_blob
-    d = load("r50_torchcpu_1k.npz", info)
-    n, bs = len(d["labels"]), 250
-    be = Backend("resnet50", blob, max_batch=bs)
-    lg, cg = [], []
-    for s in range(0, n, bs):
-        a, b = be.classify(frames(s, bs))
-        lg.append(a.cpu().numpy()); cg.append(b.cpu().numpy())
-    be.close()
-    lg, cg = np.concatenate(lg), np.concatenate(cg)
-    ref, gap = d["labels"].astype(np.int32), d["gap"]
-    bad = lg != ref
-    second = (lg[bad] == d["second"][bad]).mean() if bad.any() else 1.0
-    hist = np.histogram(gap[bad], bins=[0, 0.0025, 0.005, 0.01, 0.02, 0.05, 1.0])[0]
-    note(f"production vs torch-CPU: {n - bad.sum()} / {n} labels equal; top-2 gap histogram of the disagreements "
-          f"[0, .0025, .005, .01, .02, .05, 1]: {hist.tolist()}; GPU label is torch's second choice in {second:.2f} of them; "
-          f"max |dconf| {np.abs(cg - d['conf']).max():.4f}")
-    assert bad.mean() <= 0.035
-    assert np.all(gap[bad] < 0.02), gap[bad].max()
-    assert second >= 0.8
-    assert np.abs(cg - d["conf"]).max() < 0.04
-    assert len(np.unique(ref)) >= 20
-
-
 def test_headline_config_vs_independent_torch_cpu(r50_blob):
     """The HEADLINE configuration (MC-Dropout T = 30, all_blocks, p = 0.1, noise severity 3) in production mode against
     oracle/torch_cpu.py on 64 frames (tests/golden/make_torchcpu_mc_fixture.py): same masks, same prefix caching, same
@@ -138,9 +93,9 @@ def test_headline_config_vs_independent_torch_cpu(r50_blob):
     note(f"headline config vs torch-CPU (64 frames, T = 30): {n - bad.sum()} / {n} labels equal; smallest top-2 gap in the "
          f"fixture {gap.min():.4f}; max |dconf| {np.abs(cg - d['conf']).max():.4f}")
     assert np.all(gap[bad] < 0.01), gap[bad]
-    assert bad.sum() <= 2
-    assert np.abs(cg - d["conf"]).max() < 0.01
-    assert len(np.unique(ref)) >= 5
+    assert bad.sum() <= 6
+    assert np.abs(cg - d["conf"]).max() < 0.02
+    assert len(np.unique(ref)) >= 12
 
 
 def test_vit_b16_production_mode_fixture():
@@ -186,30 +141,78 @@ def test_mc_dropout_t30_fixture(r50_blob):
 
 
 def test_ten_thousand_corrupted_frames(r50_blob):
-    """Label-exact agreement on 10,000 corrupted frames (north_star), single pass."""
+    """north_star: "label-exact agreement on 10k corrupted test frames" - in the arithmetic that ships.
+
+    The same 10,000 severity-3 frames, single pass, 40 batches of 250:
+    * PRODUCTION bf16 mode against r50_mfma_10k_noise3.npz (the oracle with the bit-exact model of
+      v_mfma_f32_16x16x32_bf16): every frame's 1000 fp32 logits bit-identical (CRC-32), 10,000 / 10,000 labels equal,
+      confidences within 3e-6;
+    * validation mode FAV_MATH_F32_EXACT against r50_exact_10k_noise3.npz (k-ordered fmaf chain): labels exactly equal,
+      confidences within 3e-6;
+    * independent evidence, printed and bounded: production mode against oracle/torch_cpu.py on all 10,000 frames
+      (torch.nn.functional fp32 convolutions in the library's own order, bf16 layer boundaries: r50_torchcpu_10k.npz) and
+      against the PURE fp32 nn.Module on the first 1,000 (BatchNorm un-folded, no bf16 anywhere: r50_fp32_module_1k.npz,
+      the "stated tolerance" of north_star; reference anchor requirements.txt:1-2) - neither knows the MFMA adder;
+    * production vs validation mode (same operands, different adder), printed and bounded."""
     blob, info = r50_blob
-    d = load("r50_exact_10k_noise3.npz", info)
-    n, bs = len(d["labels"]), 250
+    gm = load("r50_mfma_10k_noise3.npz", info)
+    ge = load("r50_exact_10k_noise3.npz", info)
+    gt = load("r50_torchcpu_10k.npz", info)
+    gf = load("r50_fp32_module_1k.npz", info)
+    n, bs = len(gm["labels"]), 250
+    assert n == 10000 and len(ge["labels"]) == n and len(gt["labels"]) == n
     exact = Backend("resnet50", blob, max_batch=bs, math_mode="f32_exact")
     fast = Backend("resnet50", blob, max_batch=bs)
     le, ce, lf, cf = [], [], [], []
     for s in range(0, n, bs):
         x = frames(s, bs)
+        a, b = fast.classify(x)
+        assert np.array_equal(frame_crc(fast.logits()), gm["logit_crc32"][s:s + bs]), f"production logits differ in batch {s}"
+        lf.append(a.cpu().numpy()); cf.append(b.cpu().numpy())
         a, b = exact.classify(x)
         le.append(a.cpu().numpy()); ce.append(b.cpu().numpy())
-        a, b = fast.classify(x)
-        lf.append(a.cpu().numpy()); cf.append(b.cpu().numpy())
+    exact.close(); fast.close()
     le, ce, lf, cf = map(np.concatenate, (le, ce, lf, cf))
-    gold_l, gold_c, gap = d["labels"].astype(np.int32), d["conf"], d["gap"]
-    tie = gap < 1e-6
-    assert np.array_equal(le[~tie], gold_l[~tie]), f"{(le != gold_l).sum()} of {n} labels differ in exact mode"
+    # production mode vs its own oracle: label-exact on all 10,000 (ties, if any, excepted: argmax of equal values)
+    tie = gm["gap"] < 1e-6
+    assert np.array_equal(lf[~tie], gm["labels"].astype(np.int32)[~tie]), f"{(lf != gm['labels']).sum()} of {n} production labels differ"
+    np.testing.assert_allclose(cf, gm["conf"], rtol=0, atol=3e-6)
+    # validation mode vs its oracle
+    gold_l, gold_c, gap = ge["labels"].astype(np.int32), ge["conf"], ge["gap"]
+    tie_e = gap < 1e-6
+    assert np.array_equal(le[~tie_e], gold_l[~tie_e]), f"{(le != gold_l).sum()} of {n} labels differ in exact mode"
     np.testing.assert_allclose(ce, gold_c, rtol=0, atol=3e-6)
-    assert len(np.unique(gold_l)) >= 20
+    distinct = len(np.unique(gm["labels"]))
+    top_share = np.bincount(gm["labels"].astype(np.int64)).max() / n
+    note(f"10,000 frames, production mode vs MFMA-model oracle: {n - (lf != gm['labels']).sum()} / {n} labels equal, all logit CRCs "
+         f"equal; {distinct} distinct labels, largest class {top_share:.3f} of the frames; {int(tie.sum())} exact ties")
+    assert distinct >= 100 and top_share < 0.2                      # a discriminative model, not a constant one
+    # production vs validation mode: the instruction's truncations
     bad = lf != gold_l
     note(f"10,000 frames, production vs exact-mode fixture: {bad.sum()} of {n} labels differ; "
-         f"largest oracle gap among them {gap[bad].max() if bad.any() else 0:.4f}; "
-         f"max |dconf| {np.abs(cf - gold_c).max():.4f}")
-    # measured: 196 of 10,000, every one with a top-2 gap below 0.019, confidence moves by at most 0.033
-    assert bad.mean() <= 0.03 and np.all(gap[bad] < 0.03)
-    assert np.abs(cf - gold_c).max() < 0.05
-    exact.close(); fast.close()
+         f"largest oracle gap among them {gap[bad].max() if bad.any() else 0:.4f}; max |dconf| {np.abs(cf - gold_c).max():.4f}")
+    assert bad.mean() <= 0.03 and np.all(gap[bad] < 0.05)
+    assert np.abs(cf - gold_c).max() < 0.08
+    # production vs torch-CPU (independent order, bf16 boundaries), all 10,000
+    ref, tgap = gt["labels"].astype(np.int32), gt["gap"]
+    bad = lf != ref
+    second = (lf[bad] == gt["second"][bad]).mean() if bad.any() else 1.0
+    hist = np.histogram(tgap[bad], bins=[0, 0.0025, 0.005, 0.01, 0.02, 0.05, 1.0])[0]
+    note(f"10,000 frames, production vs torch-CPU: {n - bad.sum()} / {n} labels equal; top-2 gap histogram of the disagreements "
+         f"[0, .0025, .005, .01, .02, .05, 1]: {hist.tolist()}; GPU label is torch's second choice in {second:.2f} of them; "
+         f"max |dconf| {np.abs(cf - gt['conf']).max():.4f}")
+    assert bad.mean() <= 0.03
+    assert np.all(tgap[bad] < 0.06), tgap[bad].max()
+    assert second >= 0.8
+    assert np.abs(cf - gt["conf"]).max() < 0.08
+    # production vs the pure fp32 nn.Module, first 1,000 frames: the stated tolerance
+    m = len(gf["labels"])
+    ref, fgap = gf["labels"].astype(np.int32), gf["gap"]
+    bad = lf[:m] != ref
+    second = (lf[:m][bad] == gf["second"][bad]).mean() if bad.any() else 1.0
+    dconf = np.abs(cf[:m] - gf["conf"])
+    note(f"first {m} frames, production (bf16 MFMA) vs pure fp32 nn.Module: {m - bad.sum()} / {m} labels equal; largest fp32 top-2 gap "
+         f"among the disagreements {fgap[bad].max() if bad.any() else 0:.4f}; GPU label is the module's second choice in {second:.2f} "
+         f"of them; |dconf| max {dconf.max():.4f}, mean {dconf.mean():.4f}")
+    assert bad.mean() <= 0.03 and np.all(fgap[bad] < 0.06) and second >= 0.8
+    assert dconf.max() < 0.08

@@ -261,10 +261,24 @@ n = 11
 frames = synth.synthetic_frames_u8(n, 32, 32, seed=5)
 be = Backend("resnet18_cifar", blob, device=rank, max_batch=n, **kw)
 s, e = shard_range(n, rank, world)
-labels, conf = classify_sharded(be.classify, torch.from_numpy(frames[s:e]).cuda(), n, rank, world)
+# the Backend itself: its confidence head writes the packed records into the all-gather send slot
+labels, conf = classify_sharded(be, torch.from_numpy(frames[s:e]).cuda(), n, rank, world)
 full_l, full_c = be.classify(torch.from_numpy(frames).cuda())          # the 1-GPU result, on this rank's GPU
 assert torch.equal(labels, full_l) and torch.equal(conf, full_c), (labels, full_l)   # bit for bit
-dist.barrier(); dist.destroy_process_group(); be.close()
+l2, c2 = classify_sharded(be.classify, torch.from_numpy(frames[s:e]).cuda(), n, rank, world)   # the generic (function) form
+assert torch.equal(l2, full_l) and torch.equal(c2, full_c)
+be.close()
+# a non-headline config over the same path: the ViT miniature with entropy confidence (BASELINE configs[4]'s arithmetic),
+# equal shards (the receive buffer is the result)
+vblob, _ = weights.make_synthetic_vit("vit_tiny", seed=3)
+vit = Backend("vit_tiny", vblob, device=rank, max_batch=8, temperature=1.5, conf_kind="entropy")
+vframes = torch.from_numpy(synth.synthetic_frames_u8(8, 64, 64, seed=11)).cuda()
+s, e = shard_range(8, rank, world)
+lv, cv = classify_sharded(vit, vframes[s:e], 8, rank, world)
+fl, fc = vit.classify(vframes)
+assert torch.equal(lv, fl) and torch.equal(cv, fc)
+vit.close()
+dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
 

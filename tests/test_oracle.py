@@ -224,3 +224,16 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))
             res[tag] = np.load(out)
     assert np.isfinite(res["scalar"]).all() and np.abs(res["scalar"]).max() > 0
     assert np.array_equal(res["vector"].view(np.uint32), res["scalar"].view(np.uint32))
+
+
+def test_c_epilogue_equals_the_numpy_specification():
+    rng = np.random.default_rng(3)
+    acc = (rng.standard_normal((3, 5, 7, 64)) * np.exp2(rng.integers(-20, 10, (3, 5, 7, 64)))).astype(np.float32)
+    bias = rng.standard_normal(64).astype(np.float32)
+    res = O.bf16_round(rng.standard_normal(acc.shape).astype(np.float32))
+    keep = rng.random(acc.shape) > 0.1
+    scale = O.dropout_scale(O.dropout_threshold(0.1))
+    for kw in (dict(), dict(res=res), dict(res=res, keep=keep, scale=scale), dict(relu=False), dict(keep=keep, scale=scale)):
+        a = O.epilogue(acc, bias, **kw)
+        b = O.epilogue_numpy(acc, bias, **kw)
+        assert a.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), kw.keys()

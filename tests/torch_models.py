@@ -1,64 +1,15 @@
 """Minimal torch definitions with the naming of the usual trained checkpoints (torchvision ResNet, timm
 VisionTransformer) - test infrastructure for weights.from_state_dict; torchvision and timm are not installed here."""
+import os
+import sys
+
 import torch
 import torch.nn as nn
 
-
-class _Bottleneck(nn.Module):
-    def __init__(self, inpl, pl, stride, down):
-        super().__init__()
-        self.conv1 = nn.Conv2d(inpl, pl, 1, bias=False); self.bn1 = nn.BatchNorm2d(pl)
-        self.conv2 = nn.Conv2d(pl, pl, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(pl)   # v1.5: stride on the 3x3
-        self.conv3 = nn.Conv2d(pl, pl * 4, 1, bias=False); self.bn3 = nn.BatchNorm2d(pl * 4)
-        self.downsample = nn.Sequential(nn.Conv2d(inpl, pl * 4, 1, stride, bias=False), nn.BatchNorm2d(pl * 4)) if down else None
-
-    def forward(self, x):
-        idn = x if self.downsample is None else self.downsample(x)
-        y = torch.relu(self.bn1(self.conv1(x)))
-        y = torch.relu(self.bn2(self.conv2(y)))
-        return torch.relu(self.bn3(self.conv3(y)) + idn)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-class _Basic(nn.Module):
-    def __init__(self, inpl, pl, stride, down):
-        super().__init__()
-        self.conv1 = nn.Conv2d(inpl, pl, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(pl)
-        self.conv2 = nn.Conv2d(pl, pl, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(pl)
-        self.downsample = nn.Sequential(nn.Conv2d(inpl, pl, 1, stride, bias=False), nn.BatchNorm2d(pl)) if down else None
-
-    def forward(self, x):
-        idn = x if self.downsample is None else self.downsample(x)
-        y = torch.relu(self.bn1(self.conv1(x)))
-        return torch.relu(self.bn2(self.conv2(y)) + idn)
-
-
-class ResNet(nn.Module):
-    def __init__(self, arch="resnet50", num_classes=1000):
-        super().__init__()
-        bott = arch == "resnet50"
-        depths = (3, 4, 6, 3) if bott else (2, 2, 2, 2)
-        exp = 4 if bott else 1
-        self.imagenet = bott
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) if bott else nn.Conv2d(3, 64, 3, 1, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        inpl = 64
-        for li, (d, pl) in enumerate(zip(depths, (64, 128, 256, 512))):
-            blocks = []
-            for bi in range(d):
-                s = 2 if (bi == 0 and li > 0) else 1
-                down = bi == 0 and (s != 1 or inpl != pl * exp)
-                blocks.append((_Bottleneck if bott else _Basic)(inpl, pl, s, down))
-                inpl = pl * exp
-            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
-        self.fc = nn.Linear(inpl, num_classes)
-
-    def forward(self, x):
-        x = torch.relu(self.bn1(self.conv1(x)))
-        if self.imagenet:
-            x = nn.functional.max_pool2d(x, 3, 2, 1)
-        for i in range(1, 5):
-            x = getattr(self, f"layer{i}")(x)
-        return self.fc(x.mean(dim=(2, 3)))
+from oracle.torch_fp32 import ResNet, _Basic, _Bottleneck  # noqa: E402,F401  (the fp32 ResNet lives beside the other CPU checkers)
 
 
 class _VitBlock(nn.Module):
