@@ -83,3 +83,33 @@ def test_vit_state_dict_converts_to_the_same_function():
     assert rel_rms(lg[0], ref) < 0.03, rel_rms(lg[0], ref)
     sblob, _ = weights.make_synthetic_vit("vit_tiny", seed=3, num_classes=50)
     assert len(blob) == len(sblob)
+
+
+def test_synthetic_checkpoint_is_an_fp32_state_dict_and_the_blob_is_its_fold():
+    """weights.make_synthetic_state_dict: the synthetic checkpoint as a plain fp32 torch state_dict.  The nn.Module of
+    oracle/torch_fp32.py loads it strictly; folding it (from_state_dict) gives make_synthetic's blob bit for bit; and the
+    module's pure fp32 forward agrees with the oracle's bf16-boundary forward up to that rounding."""
+    from oracle import torch_fp32 as TF
+    sd, meta = weights.make_synthetic_state_dict("resnet18_cifar", seed=1)
+    assert all(v.dtype == np.float32 for v in sd.values())
+    blob, info = weights.make_synthetic("resnet18_cifar", seed=1)
+    blob2, info2 = weights.from_state_dict("resnet18_cifar", sd, bn_eps=meta["bn_eps"])
+    assert blob2 == blob and info2["sha256"] == info["sha256"]
+    net, _ = TF.load_synthetic("resnet18_cifar", seed=1)              # strict load
+    frames = synth.synthetic_frames_u8(32, 32, 32, seed=9)
+    cfg = O.ClassifyConfig()
+    labels, conf, lg, pb = O.classify(O.parse_blob(blob), frames, cfg, return_logits=True)
+    xn = (frames.astype(np.float32) / 255.0 - np.asarray(cfg.mean, np.float32)) / np.asarray(cfg.std, np.float32)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(xn.transpose(0, 3, 1, 2).copy())).numpy()
+    assert rel_rms(lg[0], ref) < 0.03, rel_rms(lg[0], ref)
+    gap = np.sort(pb, axis=1)
+    gap = gap[:, -1] - gap[:, -2]
+    same = labels == ref.argmax(axis=1)
+    assert np.all(gap[~same] < 0.05) and same.mean() >= 0.9
+    assert len(set(labels.tolist())) >= 5                               # the head reads content, not a constant
+    # the MC-Dropout runner of the CPU baseline: a probability vector per frame, and it reduces to the plain forward at T = 1
+    p1 = TF.mc_dropout_probs(net, torch.from_numpy(xn.transpose(0, 3, 1, 2).copy()), 1, 0, 0.0)
+    assert np.allclose(p1.numpy(), torch.softmax(torch.from_numpy(ref), dim=1).numpy(), atol=1e-6)
+    p8 = TF.mc_dropout_probs(net, torch.from_numpy(xn.transpose(0, 3, 1, 2).copy()), 8, weights.site_mask_for(0, "all_blocks"), 0.1)
+    assert p8.shape == (32, 10) and np.allclose(p8.sum(dim=1).numpy(), 1.0, atol=1e-5)
