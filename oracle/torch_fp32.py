@@ -91,14 +91,32 @@ def blocks_of(net):
     return [b for i in range(1, 5) for b in getattr(net, f"layer{i}")]
 
 
+def fuse_for_inference(net):
+    """What a PyTorch user does before serving a ResNet: every conv + eval-mode BatchNorm pair becomes one fp32
+    convolution with a bias (torch.nn.utils.fusion.fuse_conv_bn_eval).  Still fp32 everywhere, no bf16."""
+    import copy
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+    net = copy.deepcopy(net).eval()
+    net.conv1 = fuse_conv_bn_eval(net.conv1, net.bn1); net.bn1 = nn.Identity()
+    for b in blocks_of(net):
+        for k in (1, 2, 3):
+            if hasattr(b, f"conv{k}"):
+                setattr(b, f"conv{k}", fuse_conv_bn_eval(getattr(b, f"conv{k}"), getattr(b, f"bn{k}")))
+                setattr(b, f"bn{k}", nn.Identity())
+        if b.downsample is not None:
+            b.downsample = nn.Sequential(fuse_conv_bn_eval(b.downsample[0], b.downsample[1]), nn.Identity())
+    return net.to(memory_format=torch.channels_last)
+
+
 @torch.no_grad()
-def mc_dropout_probs(net, x_nchw, n_samples, site_mask, p, generator=None):
+def mc_dropout_probs(net, x_nchw, n_samples, site_mask, p, chunk=96):
     """Mean over T dropout samples of softmax(logits) -> [B, classes].  Sites as in the GPU path: bit s = output of
     residual block s, bit n_blocks = pooled features; everything up to and including the first site's block runs
-    once, the T samples of the rest run as ONE stacked batch (what a many-core host runs best)."""
+    once, the T samples of the rest run stacked, `chunk` virtual frames at a time (one stacked batch of T x B frames
+    does not fit the caches of a CPU; F.dropout in place draws torch's own masks)."""
     blocks = blocks_of(net)
     nb = len(blocks)
-    x = torch.relu(net.bn1(net.conv1(x_nchw)))
+    x = torch.relu_(net.bn1(net.conv1(x_nchw)))
     if net.imagenet:
         x = nn.functional.max_pool2d(x, 3, 2, 1)
     sites = [s for s in range(nb + 1) if site_mask >> s & 1]
@@ -110,15 +128,20 @@ def mc_dropout_probs(net, x_nchw, n_samples, site_mask, p, generator=None):
     for i in range(min(first + 1, nb)):
         x = blocks[i](x)
     bsz = x.shape[0]
-    x = x.repeat(n_samples, 1, 1, 1)                       # T copies of the cached prefix output
-    drop = lambda t: nn.functional.dropout(t, p, training=True)
-    if first < nb:
-        x = drop(x)
-    for i in range(first + 1, nb):
-        x = blocks[i](x)
-        if site_mask >> i & 1:
-            x = drop(x)
-    f = x.mean(dim=(2, 3))
-    if site_mask >> nb & 1:
-        f = drop(f)
-    return torch.softmax(net.fc(f), dim=1).reshape(n_samples, bsz, -1).mean(dim=0)
+    drop = lambda t: nn.functional.dropout(t, p, training=True, inplace=True)
+    probs = torch.zeros(bsz, net.fc.out_features)
+    per = max(1, chunk // n_samples) if chunk < n_samples * bsz else bsz     # frames whose T samples run together
+    for f0 in range(0, bsz, per):
+        xs = x[f0:f0 + per].repeat(n_samples, 1, 1, 1)           # T copies of the cached prefix output
+        if first < nb:
+            xs = drop(xs)
+        for i in range(first + 1, nb):
+            xs = blocks[i](xs)
+            if site_mask >> i & 1:
+                xs = drop(xs)
+        f = xs.mean(dim=(2, 3))
+        if site_mask >> nb & 1:
+            f = drop(f)
+        nf = xs.shape[0] // n_samples
+        probs[f0:f0 + nf] = torch.softmax(net.fc(f), dim=1).reshape(n_samples, nf, -1).mean(dim=0)
+    return probs

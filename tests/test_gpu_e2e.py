@@ -294,8 +294,7 @@ def test_records_entry_and_calls_on_different_streams(r18_blob):
         be.classify_records(frames, out=torch.empty((n, 2), dtype=torch.int64, device="cuda"))
     # two streams, no host synchronisation in between
     half = frames_np[:32]
-    lh_ref, ch_ref = be.classify(half)
-    lh_ref, ch_ref = lh_ref.cpu().numpy(), ch_ref.cpu().numpy()
+    lh_ref, ch_ref = be.classify(half)                       # numpy in -> numpy out
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     for _ in range(5):
