@@ -25,11 +25,13 @@ class _Bottleneck(nn.Module):
         self.conv3 = nn.Conv2d(pl, pl * 4, 1, bias=False); self.bn3 = nn.BatchNorm2d(pl * 4)
         self.downsample = nn.Sequential(nn.Conv2d(inpl, pl * 4, 1, stride, bias=False), nn.BatchNorm2d(pl * 4)) if down else None
 
-    def forward(self, x):
+    def forward(self, x):                                  # in-place add and ReLU, as torchvision's Bottleneck (ReLU(inplace=True), out += identity)
         idn = x if self.downsample is None else self.downsample(x)
-        y = torch.relu(self.bn1(self.conv1(x)))
-        y = torch.relu(self.bn2(self.conv2(y)))
-        return torch.relu(self.bn3(self.conv3(y)) + idn)
+        y = torch.relu_(self.bn1(self.conv1(x)))
+        y = torch.relu_(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        y += idn
+        return torch.relu_(y)
 
 
 class _Basic(nn.Module):
@@ -41,8 +43,10 @@ class _Basic(nn.Module):
 
     def forward(self, x):
         idn = x if self.downsample is None else self.downsample(x)
-        y = torch.relu(self.bn1(self.conv1(x)))
-        return torch.relu(self.bn2(self.conv2(y)) + idn)
+        y = torch.relu_(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y += idn
+        return torch.relu_(y)
 
 
 class ResNet(nn.Module):
@@ -66,7 +70,7 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(inpl, num_classes)
 
     def forward(self, x):
-        x = torch.relu(self.bn1(self.conv1(x)))
+        x = torch.relu_(self.bn1(self.conv1(x)))
         if self.imagenet:
             x = nn.functional.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):
