@@ -404,7 +404,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
         const int HBM = halo_cfg == 0 ? 128 : 256;
         const int wstages = d.Cin == 64 ? (halo_cfg == 0 ? 2 : 3) : (halo_cfg == 0 ? 2 : 4);   // K tiles of weights held in LDS
         const int patch_bytes = (int)((((long long)(HBM + 2 * d.W + 2) * d.Cin * 2) + 1023) / 1024 * 1024);
-        const int lds = patch_bytes + wstages * d.Cout * 128 + d.Cout * 5 + 16;
+        const int lds = patch_bytes + wstages * d.Cout * 128 + d.Cout * 5 + 512;   // + 256 zero bytes on a 256-byte boundary
         if (lds <= 160 * 1024) {
             p.nk = 9 * d.Cin / 64;
             dim3 hgrid((unsigned)((p.M + HBM - 1) / HBM));
@@ -496,7 +496,7 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
         // 8 waves x 32 pixels, Wc double-buffered (2 x 64 KB), one block per CU: 1.14 ms against 1.24 ms for 4 waves with a
         // single Wc buffer at two blocks per CU and 1.27 ms for the generic kernel (profiles/r2j_tail_l4.txt)
         g->patch_bytes = 0; g->rega_bytes = 0; g->nw = 8; g->rp = 32; g->wc2 = 1;
-        g->lds_bytes = 2 * 65536 + (cmid + 4 * cmid) * 5 + 16;
+        g->lds_bytes = 2 * 65536 + (cmid + 4 * cmid) * 5 + 512;
         return true;
     }
     else if (cmid == 256) { if ((has3x3 && nred != 0) || !(nred == 0 || nred == 256)) return false; }
@@ -504,7 +504,7 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     if (cmid == 256 && has3x3) {
         // conv_b as the generic 256 x 256 x 64 loop (two 64 KB stages); T2, then the Wc buffers, reuse those 128 KB
         g->patch_bytes = 0; g->rega_bytes = 128 * 1024; g->nw = 8; g->rp = 32; g->wc2 = 1;
-        g->lds_bytes = g->rega_bytes + (cmid + 4 * cmid) * 5 + 16;
+        g->lds_bytes = g->rega_bytes + (cmid + 4 * cmid) * 5 + 512;
         return true;
     }
     const int rp = (cmid == 256 && nred == 256) ? 16 : 32;
@@ -513,7 +513,7 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     // region A: patch | T2 tile | Y chunk; without conv_b the T2 fragments come straight from global memory
     int rega = has3x3 ? std::max(std::max(patch, bm * 128), bm * rowb) : (nred > 0 ? bm * 128 : 0);
     rega = (rega + 1023) / 1024 * 1024;
-    const int tail = (cmid + 4 * cmid + nred) * 5 + 16;
+    const int tail = (cmid + 4 * cmid + nred) * 5 + 512;    // biases + 256 zero bytes on a 256-byte boundary
     // Wc double-buffered when two blocks still fit a CU (4-wave blocks) / the block fits at all (8-wave blocks)
     const int ring = has3x3 ? ns * cmid * 128 : 0;
     const int budget = nw == 4 ? 80 * 1024 : 160 * 1024;

@@ -903,7 +903,11 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
     // [patch | NS*SUB weight K tiles | bias (16-channel chunks, 20 floats apart) | 16 zero bytes]; the fp32 staging of the epilogue overlays the patch
     unsigned char* const Bring = hsm + patch_bytes;
     float* const bias_s = (float*)(Bring + NS * SUB * B_BYTES);
-    const uint32_t zero_off = (uint32_t)(patch_bytes + NS * SUB * B_BYTES + BN * 5);
+    // 256 zero bytes on a 256-byte boundary: a lane whose tap leaves the frame reads the zero region at the SAME 16-byte
+    // slot of the bank row its patch address has (zero_off | (address & 0xF0)), so the 16 lanes a ds_read_b128 is served in
+    // keep their 16 distinct slots - one shared 16-byte zero slot collided with a valid lane's bank at every frame border
+    // (8-12 % of the LDS cycles of these kernels were bank-conflict cycles, profiles/r3g_lds_zero_region_ab.txt)
+    const uint32_t zero_off = ((uint32_t)(patch_bytes + NS * SUB * B_BYTES + BN * 5) + 255u) & ~255u;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
     const int m0 = tile * BM;
     if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
     if (tid < BN) bias_s[(tid >> 4) * 20 + (tid & 15)] = p.bias[tid];
-    if (tid < 4) ((uint32_t*)(hsm + zero_off))[tid] = 0u;
+    if (tid < 64) ((uint32_t*)(hsm + zero_off))[tid] = 0u;
 
     const uint32_t lds_base =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)hsm);
@@ -1012,16 +1016,15 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
                 const int q = wm * WTM + b * 16 + frow + tapoff;
                 const int sw = (CPR == 8) ? (q & 7) : ((q & 7) | ((q & 1) << 3));
                 const uint32_t ad = (uint32_t)q * ROWB + (uint32_t)(((cb * 8 + fq) ^ sw) << 4);
-                a_addr[b] = ((tapmask[b] >> tap) & 1u) ? ad : zero_off;
+                a_addr[b] = ((tapmask[b] >> tap) & 1u) ? ad : (zero_off | (ad & 0xF0u));
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 fx[TM], fw[TN];
 #pragma unroll
                 for (int b = 0; b < TM; ++b) {
-                    // chunk + 4 flips bit 2 of the (swizzled) chunk index: address ^ 64; the zero slot is read as is
-                    const uint32_t ad = (a_addr[b] == zero_off) ? zero_off : (a_addr[b] ^ (uint32_t)(kk << 6));
-                    fx[b] = *(const uint4*)(hsm + ad);
+                    // chunk + 4 flips bit 2 of the (swizzled) chunk index: address ^ 64 (inside the zero region too)
+                    fx[b] = *(const uint4*)(hsm + (a_addr[b] ^ (uint32_t)(kk << 6)));
                 }
 #pragma unroll
                 for (int a = 0; a < TN; ++a) {
@@ -1238,7 +1241,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     float* const bias_b_s = (float*)(tsm + bias_off);
     float* const bias_c_s = bias_b_s + (CMID / 16) * 20;
     float* const bias_a_s = bias_c_s + (COUT / 16) * 20;
-    const uint32_t zero_off = (uint32_t)(bias_off + (CMID + COUT + NRED) * 5);
+    const uint32_t zero_off = ((uint32_t)(bias_off + (CMID + COUT + NRED) * 5) + 255u) & ~255u;   // 256 zero bytes, see conv3x3_halo_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN1, wn = wave % WN1;
@@ -1281,7 +1284,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             if (i < NRED) bias_a_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + NBC + k];                             \
         }                                                                                                         \
     } while (0)
-    if (tid < 4) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
+    if (tid < 64) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
     // the residual of chunk 0 comes from HBM: requested now, it lands under conv_b instead of in front of P2's first epilogue
     const __amdgpu_buffer_rsrc_t srd_res =
         __builtin_amdgcn_make_buffer_rsrc((void*)((HAS_RES ? p.res : p.y) + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
@@ -1477,16 +1480,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 const int q = wm * 64 + b * 16 + frow + tapoff;
                 const int sw = tail_sw<CPR>(q);
                 const uint32_t ad = (uint32_t)q * ROWB + (uint32_t)(((cb * 8 + fq) ^ sw) << 4);
-                a_addr[b] = ((tapmask[b] >> tap) & 1u) ? ad : zero_off;
+                a_addr[b] = ((tapmask[b] >> tap) & 1u) ? ad : (zero_off | (ad & 0xF0u));
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 fx[TM], fw[TN1];
 #pragma unroll
-                for (int b = 0; b < TM; ++b) {
-                    const uint32_t ad = (a_addr[b] == zero_off) ? zero_off : (a_addr[b] ^ (uint32_t)(kk << 6));
-                    fx[b] = *(const uint4*)(tsm + ad);
-                }
+                for (int b = 0; b < TM; ++b) fx[b] = *(const uint4*)(tsm + (a_addr[b] ^ (uint32_t)(kk << 6)));
 #pragma unroll
                 for (int a = 0; a < TN1; ++a) {
                     const int row = wn * (CMID / WN1) + a * 16 + frow;
