@@ -246,11 +246,8 @@ int conv_bk(int kh, int kw, int K, bool has_res) {
     return (kh * kw > 1 || (!has_res && K >= 512) || K >= 1024) ? 64 : 32;   // K >= 1024 with a residual: the ViT MLP's second GEMM
 }
 
-int conv_ns(int bk) {
-    static int forced = [] { const char* e = getenv("FAV_CONV_NS"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 4) return (bk == 64 && forced == 4) ? 3 : forced;
-    return bk == 32 ? 3 : 2;
-}
+// ring depth: three 32-deep stages or two 64-deep ones (the other depths measured no better; their
+// instantiations were dropped in round 3) - fixed in the launch table of launch_conv
 
 // M-tile height: 256-row tiles (8 waves, 96 KB of LDS, one block per CU) raise the
 // FLOPs per byte staged from L2 for the MFMA-bound 3x3 convolutions; everything else
@@ -435,7 +432,6 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     }
     dim3 grid((unsigned)tiles);
     p.nk = p.K / BK;
-    const int NS = conv_ns(BK);
     // FAV_CONV_EPI=0 selects the round-1 epilogue (fp32 staging through LDS) for A/B measurements
     // measured (profiles/r2b_conv_epilogue_ab.txt): the register epilogue wins 2-4 % on the 3x3 and K >= 512 launches
     // (also with a residual on the 256 x 256 tile: layer 4's expand 1.24 vs 1.29 ms) and loses ~3 % on the 128-row
@@ -447,16 +443,10 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
         if (epi) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 1>), grid, dim3(256), 0, s, p); \
         else hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 0>), grid, dim3(256), 0, s, p);     \
     } while (0)
-#define FAV_LAUNCH_NS(BN_, BK_, MODE_)                                                            \
-    do {                                                                                          \
-        if (NS == 2) FAV_LAUNCH(BN_, BK_, 2, MODE_);                                              \
-        else if (NS == 3) FAV_LAUNCH(BN_, BK_, 3, MODE_);                                         \
-        else FAV_LAUNCH(BN_, BK_, 4, MODE_);                                                      \
-    } while (0)
 #define FAV_LAUNCH_MODE(MODE_)                                                                    \
     do {                                                                                          \
-        if (BN == 128) { if (BK == 32) FAV_LAUNCH_NS(128, 32, MODE_); else FAV_LAUNCH_NS(128, 64, MODE_); } \
-        else { if (BK == 32) FAV_LAUNCH_NS(64, 32, MODE_); else FAV_LAUNCH_NS(64, 64, MODE_); }   \
+        if (BN == 128) { if (BK == 32) FAV_LAUNCH(128, 32, 3, MODE_); else FAV_LAUNCH(128, 64, 2, MODE_); } \
+        else { if (BK == 32) FAV_LAUNCH(64, 32, 3, MODE_); else FAV_LAUNCH(64, 64, 2, MODE_); }   \
     } while (0)
 #define FAV_LAUNCH_BIG(MODE_)                                                                                     \
     do {                                                                                                          \
@@ -470,7 +460,6 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     } else if (d.math_mode == FAV_MATH_BF16) FAV_LAUNCH_MODE(0); else FAV_LAUNCH_MODE(1);
 #undef FAV_LAUNCH_BIG
 #undef FAV_LAUNCH_MODE
-#undef FAV_LAUNCH_NS
 #undef FAV_LAUNCH
     dbg_report(tiles, BM, BN, BK);
     return nullptr;
