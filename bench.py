@@ -315,7 +315,7 @@ def measure(be, frames, n_total, rank, world, steps, warmup, torch, dist, classi
         prof = be.get_profile()
     be.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, lat_ms, prof, labels, prof_wall
@@ -400,6 +400,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-repeats", type=int, default=2, help="timed repeats of the CPU baseline")
     ap.add_argument("--cpu-port-frames", type=int, default=4, help="frames of the oracle-port CPU figure (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = the CPUs this job may use)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse the N > 1 path with all ranks on ONE GPU (records cross the host; not a measurement)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs and the seam latency")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args(argv)
@@ -429,9 +431,15 @@ def main():
     import torch.distributed as dist
     from failure_aware_vision_amd import Backend, classify_sharded, shard_range, synth, weights
 
+    rehearsal = world > 1 and args.dist_backend == "gloo"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     name = args.config or "mc30"
     c = config_table(args)[name]
@@ -458,7 +466,7 @@ def main():
             "metric": c["metric"],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": c["scaling"],
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic" + (" (REHEARSAL: gloo, ranks share a GPU - not a measurement)" if rehearsal else ""),
             "p50_latency_ms": statistics.median(lat_ms),
             "config": {"workload": c["workload"],
                        "frames_per_gpu": n_local, "global_batch": n_total, "mc_samples": T,

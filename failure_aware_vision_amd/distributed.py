@@ -69,7 +69,13 @@ def classify_sharded(classifier, local_frames, n_total: int, rank: int, world: i
     if world == 1:
         return unpack_records(send[:n_local]) if not direct else (send[:n_local, 0], send[:n_local, 1].view(torch.float32))
     recv = torch.empty((world * cap, 2), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # rehearsal only (several ranks sharing one GPU, where RCCL cannot run): the 8-byte records cross the host
+        host = torch.empty((world * cap, 2), dtype=torch.int32)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        recv.copy_(host)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
     if n_total == world * cap:                 # equal shards: the receive buffer IS the result
         return recv[:, 0], recv[:, 1].view(torch.float32)
     parts = []
