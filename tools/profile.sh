@@ -6,7 +6,7 @@ CFG=${2:-mc30}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-extra --no-profile"
+BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 --cpu-port-frames 0 --no-extra --no-profile"
 if [ "$CFG" != "mc30" ]; then BENCH="python3 bench.py --config $CFG --steps 5 --warmup 2 --no-profile"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"

@@ -50,7 +50,7 @@ if fn and wn:
     d = {"kernel_source_sha256": bench.kernel_source_sha(),   # the sources these counters were measured on
          "conv_fetch_bytes_per_launch": fetch, "conv_write_bytes_per_launch": write,
          "conv_bytes_per_launch": fetch + write, "launches_profiled": fn,
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-extra --no-profile`, "
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 --cpu-frames 0 --cpu-port-frames 0 --no-extra --no-profile`, "
                    "FETCH_SIZE x2 (gfx950 correction), " + os.path.basename(out.rstrip('/'))}
     json.dump(d, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("pmc_traffic", d)
