@@ -349,7 +349,10 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     // (profiles/r2g_vit_knobs.txt) 128-row tiles with 32-deep steps at three blocks per CU beat the 256 x 256 tile (the GELU
     // epilogue has nothing to hide behind at one block per CU) and the 64-deep steps (594 tiles do not fill 2 x 256 slots twice)
     const bool vit = h && h->vit;
-    const bool big = !vit && conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
+    // ViT: the 256 x 256 tile only for launches with >= FAV_VIT_BIG_TILES of them (default: never at the per-GPU share of 64 frames, see below)
+    static const long long vit_big_tiles = [] { const char* e = getenv("FAV_VIT_BIG_TILES"); return e ? atoll(e) : 512ll; }();
+    const bool vit_big = vit && (M / 256) * (cout_pad / 256) >= vit_big_tiles;
+    const bool big = (!vit || vit_big) && conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
     const int BK = big ? 64 : (vit ? 32 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr));
     const int BM = big ? 256 : conv_bm(d.kh, d.kw, M);
