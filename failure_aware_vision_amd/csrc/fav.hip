@@ -567,6 +567,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
     const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
+    { static const int lds_pad = [] { const char* e = getenv("FAV_TAIL_LDS_PAD"); return e ? atoi(e) : 0; }(); if (g.lds_bytes + lds_pad <= 160 * 1024) g.lds_bytes += lds_pad; }   // experiments: fewer blocks per CU
     const int bm = g.rp * g.nw;
     const long long nblocks = (M + bm - 1) / bm;
     dim3 grid((unsigned)nblocks);
