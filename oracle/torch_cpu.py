@@ -46,10 +46,14 @@ class TorchNet:
         # dict, every generated keep mask is stored under (t, site) and reused by later calls with the same
         # arguments, so bench.py's cpu_baseline can generate them in its warm-up call, outside the timed region.
         self.mask_cache = None
+        self._call_sig = None
 
     def _cached(self, key, make):
+        """Masks are cached under (key, signature of the call they belong to): a net reused with another seed, threshold,
+        sample count or set of frames never gets the masks of an earlier call."""
         if self.mask_cache is None:
             return make()
+        key = (key, self._call_sig)
         if key not in self.mask_cache:
             self.mask_cache[key] = make()
         return self.mask_cache[key]
@@ -124,6 +128,7 @@ class TorchNet:
         thr = O.dropout_threshold(p)
         if site_mask == 0 or thr == 0:
             site_mask, n_samples, thr = 0, 1, 0
+        self._call_sig = (int(seed), int(thr), int(n_samples), int(site_mask), tuple(x.shape), tuple(int(i) for i in img_ids))
         scale = float(O.dropout_scale(thr))
         first = min((s for s in range(self.nb + 1) if site_mask >> s & 1), default=self.nb + 1)
 
