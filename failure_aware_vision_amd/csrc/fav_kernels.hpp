@@ -1196,7 +1196,9 @@ __device__ __forceinline__ int tail_sw(int row) {
 // shortcut of a stage's first block (1x1 / 2, no residual, no ReLU, no dropout).
 template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32, int COUT_ = 0, bool HAS_RES = true, bool RELU = true>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
-    constexpr bool LINEST = NRED > 0;   // Y is stored in whole 128-byte lines from its LDS image (P2, step C); without conv_a there is no image
+    // Y is stored in whole 128-byte lines from an LDS image of the chunk: the one conv_a reads (NRED > 0), or - behind a staged-patch
+    // conv_b, whose region A is free in P2 - an image kept for that purpose alone
+    constexpr bool LINEST = NRED > 0 || (HAS3X3 && !(HAS3X3 && CMID == 256));
     constexpr int COUT = COUT_ > 0 ? COUT_ : 4 * CMID;
     static_assert(HAS_RES || (!HAS3X3 && NRED == 0), "only conv_c alone runs without a residual");
     constexpr int BM = RP * NW, NT = NW * 64;      // every wave owns RP pixel rows in P2 (16 only without conv_b)
@@ -1697,15 +1699,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                     }
                     const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                     if (!LINEST) __builtin_amdgcn_raw_buffer_store_b128(o, srd_y, (row * COUT + n + 8 * g) * 2, 0, 0);
-                    if (NRED > 0) *(u32x4_t*)(ych + row * 128 + (((2 * fq + g) ^ (row & 7)) << 4)) = o;
+                    if (LINEST) *(u32x4_t*)(ych + row * 128 + (((2 * fq + g) ^ (row & 7)) << 4)) = o;
                 }
             }
         }
         if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 8] = __builtin_amdgcn_s_memtime();
         // -- C: acc3 += Ychunk (this wave's own rows: its LDS writes are in order, no barrier) x Wa[:, 64j .. 64j+63]^T
-        if constexpr (NRED > 0) {
+        if constexpr (LINEST) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (LINEST) {
+            {
                 // Y leaves the CU in WHOLE 128-byte lines: the wave reads its own rows of the Y-chunk image back in line order
                 // (lane l: 16-byte piece l % 8 of row 8 i + l / 8) and one store instruction covers 8 full lines, instead of 16
                 // rows x four 16-byte pieces at a 32-byte pitch (two instructions per line) straight from the accumulator layout:
@@ -1718,6 +1720,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                     __builtin_amdgcn_raw_buffer_store_b128(o, srd_y, (row * COUT + j * 64 + (lane & 7) * 8) * 2, 0, 0);
                 }
             }
+        }
+        if constexpr (NRED > 0) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 fy[TM2];
