@@ -191,8 +191,9 @@ def test_ten_thousand_corrupted_frames(r50_blob):
     bad = lf != gold_l
     note(f"10,000 frames, production vs exact-mode fixture: {bad.sum()} of {n} labels differ; "
          f"largest oracle gap among them {gap[bad].max() if bad.any() else 0:.4f}; max |dconf| {np.abs(cf - gold_c).max():.4f}")
-    assert bad.mean() <= 0.03 and np.all(gap[bad] < 0.05)
-    assert np.abs(cf - gold_c).max() < 0.08
+    # measured: 40 of 10,000, largest gap 0.041, max |dconf| 0.033
+    assert bad.mean() <= 0.008 and np.all(gap[bad] < 0.06)
+    assert np.abs(cf - gold_c).max() < 0.05
     # production vs torch-CPU (independent order, bf16 boundaries), all 10,000
     ref, tgap = gt["labels"].astype(np.int32), gt["gap"]
     bad = lf != ref
@@ -201,10 +202,11 @@ def test_ten_thousand_corrupted_frames(r50_blob):
     note(f"10,000 frames, production vs torch-CPU: {n - bad.sum()} / {n} labels equal; top-2 gap histogram of the disagreements "
          f"[0, .0025, .005, .01, .02, .05, 1]: {hist.tolist()}; GPU label is torch's second choice in {second:.2f} of them; "
          f"max |dconf| {np.abs(cf - gt['conf']).max():.4f}")
-    assert bad.mean() <= 0.03
+    # measured: 9,955 / 10,000 equal, every disagreement below a 0.05 gap, 0.98 of them torch's second choice, max |dconf| 0.026
+    assert bad.mean() <= 0.008
     assert np.all(tgap[bad] < 0.06), tgap[bad].max()
-    assert second >= 0.8
-    assert np.abs(cf - gt["conf"]).max() < 0.08
+    assert second >= 0.9
+    assert np.abs(cf - gt["conf"]).max() < 0.04
     # production vs the pure fp32 nn.Module, first 1,000 frames: the stated tolerance
     m = len(gf["labels"])
     ref, fgap = gf["labels"].astype(np.int32), gf["gap"]
@@ -214,5 +216,6 @@ def test_ten_thousand_corrupted_frames(r50_blob):
     note(f"first {m} frames, production (bf16 MFMA) vs pure fp32 nn.Module: {m - bad.sum()} / {m} labels equal; largest fp32 top-2 gap "
          f"among the disagreements {fgap[bad].max() if bad.any() else 0:.4f}; GPU label is the module's second choice in {second:.2f} "
          f"of them; |dconf| max {dconf.max():.4f}, mean {dconf.mean():.4f}")
-    assert bad.mean() <= 0.03 and np.all(fgap[bad] < 0.06) and second >= 0.8
-    assert dconf.max() < 0.08
+    # measured: 990 / 1,000 equal, largest gap 0.033, always the module's second choice, |dconf| max 0.061 / mean 0.0068
+    assert bad.mean() <= 0.02 and np.all(fgap[bad] < 0.05) and second >= 0.8
+    assert dconf.max() < 0.09 and dconf.mean() < 0.012
