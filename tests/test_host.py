@@ -406,3 +406,29 @@ def test_fused_schedule_computes_the_layer_by_layer_dataflow(lib):
     assert sum(o["kind"] == 6 for o in ops) == 1 and not any(o["kind"] == 4 for o in ops) and len({o["phase"] for o in ops}) == 3
     # the validation mode keeps the separate launches
     assert not any(o["kind"] == 5 for o in _plan(lib, 1, 0, math_mode=1))
+
+
+def test_bench_config_table_and_roofline_objects():
+    """bench.py without a GPU: every --config entry names its BASELINE config, scaling mode and roofline bound, and the
+    roofline builder turns a per-class profile into the objects the driver's line carries."""
+    import bench
+    args = bench.parse_args([])
+    table = bench.config_table(args)
+    assert set(table) == {"mc30", "single", "ens5", "vit"}
+    assert table["mc30"]["metric"] == "frames/sec, ResNet-50 MC-Dropout T=30 224x224 batch=256" and table["mc30"]["scaling"] == "weak"
+    assert abs(table["mc30"]["gflop"] - 225.098) < 0.01 and table["mc30"]["bound"] == "hbm"
+    assert table["ens5"]["scaling"] == table["vit"]["scaling"] == "strong"
+    assert table["ens5"]["global_batch"] == 256 and table["vit"]["global_batch"] == 512 and table["single"]["per_gpu"] == 256
+    for c in table.values():
+        assert "BASELINE configs[" in c["workload"]
+    prof = {k: dict(ms=0.0, flops=0.0, bytes=0.0, launches=0) for k in ("stem_im2col", "conv_igemm", "maxpool", "avgpool", "entry_dropout", "head")}
+    prof["conv_igemm"] = dict(ms=100.0, flops=8.0e13, bytes=3.5e11, launches=50)
+    prof["head"]["ms"] = 1.0
+    hbm, mfma = bench.rooflines(prof, "hbm")
+    assert hbm["bound"] == "hbm" and mfma["bound"] == "mfma"
+    assert abs(hbm["achieved"] - 3500.0) < 1e-6 and abs(hbm["frac"] - 3500.0 / 8000.0) < 1e-9 and hbm["unit"] == "GB/s"
+    assert abs(mfma["achieved"] - 800.0) < 1e-6 and abs(mfma["frac"] - 0.32) < 1e-9 and mfma["unit"] == "TFLOP/s"
+    assert abs(hbm["avg_launch_us"] - 2000.0) < 1e-6 and set(("peak", "traffic", "launches")) <= set(hbm)
+    m2, h2 = bench.rooflines(prof, "mfma", "note", wall_s=0.05)          # overlapping streams: work over wall time
+    assert m2["bound"] == "mfma" and abs(m2["achieved"] - 1600.0) < 1e-6 and abs(m2["achieved_per_launch_events"] - 800.0) < 1e-6
+    assert h2["traffic"] is None and m2["timing"] == "note"

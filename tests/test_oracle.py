@@ -237,3 +237,29 @@ def test_c_epilogue_equals_the_numpy_specification():
         a = O.epilogue(acc, bias, **kw)
         b = O.epilogue_numpy(acc, bias, **kw)
         assert a.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), kw.keys()
+
+
+def test_committed_fixtures_belong_to_the_current_checkpoint_and_oracle(r50_blob):
+    """Every ResNet-50 fixture under tests/golden/ records the checkpoint it was made with, and the first frames of the
+    10,000-frame fixtures are replayed through the oracle as it is NOW: a fixture generated by another state of the
+    oracle (a different summation order, say) or of the weights fails here, on the CPU, before any GPU run."""
+    import glob
+    import zlib
+    blob, info = r50_blob
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    names = sorted(glob.glob(os.path.join(gold, "r50_*.npz")))
+    assert len(names) >= 8
+    for path in names:
+        d = np.load(path)
+        assert str(d["blob_sha256"]) == info["sha256"], os.path.basename(path) + " was generated with a different checkpoint"
+    model = O.parse_blob(blob)
+    u8 = synth.synthetic_frames_u8(2, 224, 224, seed=21, start_id=0)
+    x = synth.gaussian_noise_f32(u8, 3, seed=3, start_id=0)
+    d = np.load(os.path.join(gold, "r50_mfma_10k_noise3.npz"))
+    l, c, lg, pb = O.classify(model, x, O.ClassifyConfig(exact="mfma"), return_logits=True)
+    crc = np.array([zlib.crc32(np.ascontiguousarray(lg[:, i, :]).tobytes()) for i in range(2)], np.uint32)
+    assert np.array_equal(crc, d["logit_crc32"][:2]), "the production-mode fixture does not match the MFMA-model oracle"
+    assert np.array_equal(l, d["labels"][:2]) and np.abs(c - d["conf"][:2]).max() < 1e-6
+    d = np.load(os.path.join(gold, "r50_exact_10k_noise3.npz"))
+    l, c = O.classify(model, x, O.ClassifyConfig(exact=True))
+    assert np.array_equal(l, d["labels"][:2]) and np.abs(c - d["conf"][:2]).max() < 1e-6
