@@ -16,6 +16,7 @@ SHAPES = [  # name, H, Cmid, Nred, has3x3
     ("L3 3x3 + conv_c 256/1024", 14, 256, 0, 1),
     ("L4 conv_c alone 512/2048", 7, 512, 0, 0),
     ("L3 conv_c + next reduce 256/1024->256", 14, 256, 256, 0),
+    ("probe 64/256 3x3+c at 28x28 (51 KB of LDS: three blocks per CU)", 28, 64, 0, 1),
 ]
 
 
