@@ -80,7 +80,7 @@ struct Layer {  // one convolution / fc
     std::vector<float*> b_m;
 };
 
-enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT, OP_TAIL, OP_ENTRY_REDUCE };
+enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT, OP_TAIL, OP_ENTRY_REDUCE, OP_STEM_POOL };
 enum BufId { B_INPUT = -1, B_PHASE_IN = -2, B_PHASE_OUT = -3, B_NONE = -4, B_A1 = 5 };  // 0..4 rotating
 
 struct Op {
@@ -684,6 +684,37 @@ void launch_maxpool(fav_handle* h, const void* x, void* y, int n, int H, int W, 
                        C, Ho, Wo);
 }
 
+// FAV_STEM_FUSED=0: the ImageNet stem as three launches (im2col rows, GEMM, max pool) instead of stem7_pool_kernel
+bool stem_fused_enabled() {
+    static const bool on = [] { const char* e = getenv("FAV_STEM_FUSED"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+// normalise + 7x7/2 conv (64 channels, weights [64][192]) + bias + ReLU + 3x3/2 max pool, frames -> [n][Hp][Wp][64] bf16
+const char* launch_stem_pool(fav_handle* h, const void* images, int layout, int n, int H, int W, const void* w, const float* bias,
+                             const float* mean, const float* istd, void* out, hipStream_t s) {
+    if (n < 1 || H < 1 || W < 1) return "stem: empty input";
+    if (layout != FAV_LAYOUT_NHWC_U8 && layout != FAV_LAYOUT_NHWC_F32) return "stem: unknown layout";
+    StemPoolParams p;
+    p.images = images; p.w = (const uint16_t*)w; p.bias = bias; p.out = (uint16_t*)out;
+    p.n = n; p.H = H; p.W = W;
+    p.Hc = conv_out(H, 7, 2, 3); p.Wc = conv_out(W, 7, 2, 3);
+    if (p.Hc < 1 || p.Wc < 1) return "stem: input too small";
+    if ((double)H * W * 12.0 >= 2147483647.0) return "stem: frame too large for 32-bit offsets";
+    p.Hp = conv_out(p.Hc, 3, 2, 1); p.Wp = conv_out(p.Wc, 3, 2, 1);
+    p.tiles_y = (p.Hp + 7) / 8; p.tiles_x = (p.Wp + 7) / 8;
+    p.tiles = (long long)n * p.tiles_y * p.tiles_x;
+    p.m0 = mean[0]; p.m1 = mean[1]; p.m2 = mean[2]; p.i0 = istd[0]; p.i1 = istd[1]; p.i2 = istd[2];
+    const double M = (double)n * p.Hc * p.Wc;
+    Prof pr(h, s, FAV_K_CONV, 2.0 * M * 64 * 192,
+            (double)n * H * W * 3 * (layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4) + 2.0 * n * p.Hp * p.Wp * 64 + 2.0 * 64 * 192);
+    // two blocks per CU (226 VGPRs, 48 KB of LDS); blocks loop over the tiles with the weights in registers
+    const unsigned blocks = (unsigned)std::min<long long>(p.tiles, 256 * 2);
+    if (layout == FAV_LAYOUT_NHWC_U8) hipLaunchKernelGGL(stem7_pool_kernel<0>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(stem7_pool_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    return nullptr;
+}
+
 void launch_avgpool(fav_handle* h, const void* x, void* y, int n, int HW, int C, const DropParams& dp, hipStream_t s) {
     const long long total = (long long)n * (C / 16);
     Prof pr(h, s, FAV_K_AVGPOOL, 0.0, 2.0 * ((double)n * HW * C + (double)n * C));
@@ -815,7 +846,18 @@ fav_status build_graph(fav_handle* h) {
         }
         return -1;
     };
-    {
+    // production math mode: the whole ImageNet stem (normalise, 7x7/2, ReLU, max pool) is one launch
+    const bool stem_fused = A.imagenet_stem && c.math_mode == FAV_MATH_BF16 && stem_fused_enabled() && !h->plan_no_fuse &&
+                            conv_out(Ho, 3, 2, 1) >= 1 && conv_out(Wo, 3, 2, 1) >= 1;
+    int stem_ops = 0;
+    if (stem_fused) {
+        Op o; o.kind = OP_STEM_POOL; o.layer = li; o.in = B_INPUT; o.out = cur; o.relu = 1;
+        o.H = H; o.W = W; o.C = 3; o.Ho = conv_out(Ho, 3, 2, 1); o.Wo = conv_out(Wo, 3, 2, 1); o.Co = 64;
+        o.in_elems = (long long)H * W * 3; o.out_elems = (long long)o.Ho * o.Wo * 64;
+        h->ops.push_back(o);
+        H = o.Ho; W = o.Wo;
+        stem_ops = 1;
+    } else {
         Op o; o.kind = OP_STEM_IM2COL; o.layer = li; o.in = B_INPUT; o.out = B_A1;
         o.H = H; o.W = W; o.C = 3; o.Ho = Ho; o.Wo = Wo; o.Co = h->layers[li].k;
         o.in_elems = (long long)H * W * 3; o.out_elems = (long long)Ho * Wo * o.Co;
@@ -824,10 +866,12 @@ fav_status build_graph(fav_handle* h) {
         g.H = Ho; g.W = Wo; g.C = h->layers[li].k; g.Ho = Ho; g.Wo = Wo; g.Co = 64;
         g.in_elems = o.out_elems; g.out_elems = (long long)Ho * Wo * 64;
         h->ops.push_back(g);
+        H = Ho; W = Wo;
+        stem_ops = 2;
     }
-    H = Ho; W = Wo;
     int C = 64;
-    if (A.imagenet_stem) {
+    if (A.imagenet_stem && !stem_fused) {
+        ++stem_ops;
         Op o; o.kind = OP_MAXPOOL; o.in = cur; o.out = other({cur});
         o.H = H; o.W = W; o.C = C; o.Ho = conv_out(H, 3, 2, 1); o.Wo = conv_out(W, 3, 2, 1); o.Co = C;
         o.in_elems = (long long)H * W * C; o.out_elems = (long long)o.Ho * o.Wo * C;
@@ -969,7 +1013,7 @@ fav_status build_graph(fav_handle* h) {
     int regroup = c.regroup_block;
     if (regroup < 0) regroup = A.bottleneck ? A.depths[0] + A.depths[1] : A.depths[0] + A.depths[1];
     regroup = std::min(regroup, h->nblocks);
-    const int regroup_op = regroup == 0 ? (A.imagenet_stem ? 3 : 2)
+    const int regroup_op = regroup == 0 ? stem_ops
                                         : (regroup >= h->nblocks ? pool_op : block_last_op[regroup - 1] + 1);
 
     // ---- phases ---------------------------------------------------------------
@@ -1027,7 +1071,7 @@ fav_status build_graph(fav_handle* h) {
     for (size_t i = 0; i < h->phases.size(); ++i) {
         Phase& p = h->phases[i];
         Op& first = h->ops[p.op_begin];
-        if (first.kind != OP_STEM_IM2COL) {
+        if (first.kind != OP_STEM_IM2COL && first.kind != OP_STEM_POOL) {
             // consumers of the phase input: every op in the phase reading the buffer the
             // previous phase's last op wrote, until that rotating buffer is overwritten
             const bool entry = first.kind == OP_ENTRY_DROPOUT || first.kind == OP_ENTRY_REDUCE;
@@ -1238,6 +1282,10 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                     if (const char* e = launch_tail(h, d, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
                     break;
                 }
+                case OP_STEM_POOL:
+                    if (const char* e = launch_stem_pool(h, buf(o.in, false, o), layout, cn, o.H, o.W, LW(o.layer), LB(o.layer), c.mean, istd,
+                                                         buf(o.out, true, o), s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
+                    break;
                 case OP_MAXPOOL:
                     launch_maxpool(h, buf(o.in, false, o), buf(o.out, true, o), cn, o.H, o.W, o.C, s);
                     break;
@@ -1887,6 +1935,12 @@ fav_status fav_op_stem_im2col(const void* images, int32_t layout, int32_t n, int
     if (!images || !out || !mean3 || !inv_std3 || kpad % 64 != 0 || kpad < kh * kw * 3) return op_done("fav_op_stem_im2col: bad argument");
     launch_stem(nullptr, images, layout, n, H, W, kh, kw, stride, pad, kpad, mean3, inv_std3, out, (hipStream_t)stream);
     return op_done(nullptr);
+}
+
+fav_status fav_op_stem_pool(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W, const void* w, const float* bias,
+                            const float* mean3, const float* inv_std3, void* out, void* stream) {
+    if (!images || !w || !bias || !mean3 || !inv_std3 || !out) return op_done("fav_op_stem_pool: null argument");
+    return op_done(launch_stem_pool(nullptr, images, layout, n, H, W, w, bias, mean3, inv_std3, out, (hipStream_t)stream));
 }
 
 fav_status fav_op_maxpool3x3s2(const void* x, void* y, int32_t n, int32_t H, int32_t W, int32_t C, void* stream) {

@@ -226,6 +226,189 @@ __global__ __launch_bounds__(256) void stem_im2col_rows_kernel(const void* __res
 }
 
 // ---------------------------------------------------------------------------
+// The ImageNet stem in one launch: normalise -> 7x7 / 2 convolution to 64 channels -> bias -> ReLU -> bf16 ->
+// 3x3 / 2 max pool.  The three-launch form (im2col rows, GEMM, pool) moves 384 B + 128 B + 128 B per conv pixel
+// through HBM; here a block owns an 8 x 8 tile of POOL pixels, i.e. a 17 x 17 tile of conv pixels on a 39 x 39 patch
+// of input pixels, and nothing but the frames and the pooled tile crosses HBM:
+//   1. the patch is normalised and rounded ONCE, into 17 column strips in LDS: strip lx holds, for each of the 39 patch
+//      rows y, the 21 values (7 pixels x 3 channels) under conv column lx.  k = (r*7 + s)*3 + c then makes the 147-long
+//      im2col row of conv pixel (ly, lx) the CONTIGUOUS run strip[lx][2*ly .. 2*ly + 6][0 .. 20], so the B fragment of
+//      k-step s is one 16-byte LDS read at 1640*lx + 84*ly + 64*s + 16*(lane / 16) - no im2col matrix, no gather
+//      arithmetic (k >= 147 is masked to zero, as the padded matrix has it).  A patch value lies in up to four strips;
+//      the thread that loaded it writes each copy at (per-thread base) + (compile-time row offset);
+//   2. the whole [64][192] weight matrix sits in registers as A fragments (96 VGPRs), loaded once per block; a wave
+//      takes 16 conv pixels x 64 channels x 6 k-steps per round - the same MFMA and the same k order as the GEMM over
+//      the im2col matrix, so the results are bit-identical to the three-launch form;
+//   3. (acc + bias) -> ReLU -> bf16 into an LDS image of the conv tile, then the max over the 3 x 3 windows (taps
+//      outside the conv map re-read the centre tap; bf16 values >= +0 order like their bit patterns: packed u16 max);
+//   4. the raw pixels of the block's NEXT tile are requested into registers before the convolution of this one.
+// ---------------------------------------------------------------------------
+struct StemPoolParams {
+    const void* images;
+    const uint16_t* w;       // [64][192] bf16, k = (r*7 + s)*3 + c, zero for k >= 147
+    const float* bias;       // [64]
+    uint16_t* out;           // [n][Hp][Wp][64] bf16
+    int n, H, W, Hc, Wc, Hp, Wp;
+    int tiles_y, tiles_x;
+    long long tiles;         // n * tiles_y * tiles_x
+    float m0, m1, m2, i0, i1, i2;
+};
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(4))) StemFrag { uint32_t x, y, z, w; };     // a 16-byte LDS read at a 4-byte aligned address
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void stem7_pool_kernel(StemPoolParams p) {
+    constexpr int PT = 8, CT = 2 * PT + 1, NPIX = CT * CT, NGRP = (NPIX + 15) / 16;
+    constexpr int PROWS = 2 * CT + 5, PVALS = PROWS * 3;          // 39 patch rows of 39 pixels = 117 values
+    constexpr int SPITCH = PROWS * 21 + 1;                        // 820 elements per strip: every window 4-byte aligned
+    constexpr int ESZ = LAYOUT == 0 ? 1 : 4;
+    __shared__ __attribute__((aligned(16))) uint16_t strip_s[CT * SPITCH + 44];   // the last pixel's k = 147..159 reads run 11 past
+    __shared__ __attribute__((aligned(16))) uint16_t conv_s[NGRP * 16 * 64];      // [conv pixel][64], 16-B units XOR-swizzled by pixel
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    uint4 wf[4][6];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wf[a][s] = *(const uint4*)(p.w + (16 * a + fr) * 192 + 32 * s + 8 * fq);
+    if (tid < 64) bias_s[tid] = p.bias[tid];
+    // k-step 4 holds k = 128 .. 159: the lanes of quarter 2 keep k = 144, 145, 146, quarter 3 nothing
+    const uint32_t km1 = fq < 2 ? 0xFFFFFFFFu : (fq == 2 ? 0x0000FFFFu : 0u), km0 = fq < 3 ? 0xFFFFFFFFu : 0u, km23 = fq < 2 ? 0xFFFFFFFFu : 0u;
+
+    // patch fill: a thread owns patch column fe = x*3 + c (128 threads per row, 117 used) of rows frow0, frow0 + 2, ...
+    const int fe = tid & 127, frow0 = tid >> 7;
+    const int fx = fe / 3, fc = fe - 3 * fx;
+    const float fmean = fc == 0 ? p.m0 : (fc == 1 ? p.m1 : p.m2);
+    const float fistd = fc == 0 ? p.i0 : (fc == 1 ? p.i1 : p.i2);
+    // the strips this column lies in: lx with 0 <= x - 2*lx <= 6; element (y, fe) of strip lx sits at 814*lx + 21*y + fe
+    const int lx_lo = fx < 6 ? 0 : (fx - 5) >> 1, lx_hi = (fx >> 1) < CT - 1 ? (fx >> 1) : CT - 1;
+    uint32_t sdst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lxj = lx_lo + j <= lx_hi ? lx_lo + j : lx_hi;       // fewer than four strips: the last one is written again
+        sdst[j] = (uint32_t)(2 * ((SPITCH - 6) * lxj + 21 * frow0 + fe));
+    }
+    const long long tiles_img = (long long)p.tiles_y * p.tiles_x;
+    const long long frame_bytes = (long long)p.H * p.W * 3 * ESZ;
+
+    constexpr int NFILL = (PROWS + 1) / 2;
+    uint32_t pv[NFILL];      // raw pixels (u8 value or fp32 bits) of the block's next tile
+    uint32_t pok = 0;        // bit i: pv[i] lies inside the frame
+#define FAV_STEM_REQUEST(TILE)                                                                           \
+    do {                                                                                                \
+        const long long tq_ = (TILE);                                                                   \
+        const long long t_ = tq_ < p.tiles ? tq_ : p.tiles - 1;                                         \
+        const long long img_ = t_ / tiles_img;                                                          \
+        const int trem_ = (int)(t_ - img_ * tiles_img);                                                 \
+        const int ty_ = trem_ / p.tiles_x, tx_ = trem_ - ty_ * p.tiles_x;                               \
+        const int iy0_ = 4 * ty_ * PT - 5 + frow0, ix_ = 4 * tx_ * PT - 5 + fx;                         \
+        const bool colok_ = fe < PVALS && (unsigned)ix_ < (unsigned)p.W;                                \
+        const __amdgpu_buffer_rsrc_t srd_ = __builtin_amdgcn_make_buffer_rsrc(                          \
+            (void*)((const char*)p.images + img_ * frame_bytes), 0, (int)frame_bytes, 0x00020000);      \
+        const int col_ = (ix_ * 3 + fc) * ESZ, rowb_ = p.W * 3 * ESZ;                                   \
+        pok = 0;                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NFILL; ++i) {                                             \
+            const int iy_ = iy0_ + 2 * i;                                                               \
+            const bool ok_ = colok_ && (unsigned)iy_ < (unsigned)p.H && (2 * i + 1 < PROWS || frow0 == 0); \
+            const uint32_t off_ = ok_ ? (uint32_t)(iy_ * rowb_ + col_) : 0x80000000u;                   \
+            if (LAYOUT == 0) pv[i] = __builtin_amdgcn_raw_buffer_load_b8(srd_, off_, 0, 0);             \
+            else pv[i] = __builtin_amdgcn_raw_buffer_load_b32(srd_, off_, 0, 0);                        \
+            pok |= ok_ ? 1u << i : 0u;                                                                  \
+        }                                                                                               \
+    } while (0)
+    FAV_STEM_REQUEST(blockIdx.x);
+
+    for (long long tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const long long img = tile / tiles_img;
+        const int trem = (int)(tile - img * tiles_img);
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int py0 = ty * PT, px0 = tx * PT;
+        if (fe < PVALS) {
+#pragma unroll
+            for (int i = 0; i < NFILL; ++i) {
+                if (2 * i + 1 >= PROWS && frow0 != 0) break;     // 39 rows: the odd rows stop one short
+                const float px = LAYOUT == 0 ? __fmul_rn((float)pv[i], 1.0f / 255.0f) : __uint_as_float(pv[i]);
+                const float val = (pok >> i & 1) ? __fmul_rn(__fsub_rn(px, fmean), fistd) : 0.f;
+                const uint16_t hb = (uint16_t)pack_bf16x2(val, 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(uint16_t*)((char*)strip_s + sdst[j] + 84 * i) = hb;
+            }
+        }
+        __syncthreads();
+        FAV_STEM_REQUEST(tile + gridDim.x);
+
+        for (int grp = wave; grp < NGRP; grp += 4) {
+            const int q = grp * 16 + fr;
+            const int qc = q < NPIX ? q : NPIX - 1;              // the last group's spare pixels recompute pixel 288; never pooled
+            const int ly = qc / CT, lx = qc - ly * CT;
+            const char* win = (const char*)strip_s + 2 * (SPITCH * lx + 42 * ly) + 16 * fq;
+            f32x4_t acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                union { uint4 u; bf16x8_t v; } ub;
+                ub.u = make_uint4(0, 0, 0, 0);
+                if (s < 5) {
+                    const StemFrag f = *(const StemFrag*)(win + 64 * s);
+                    ub.u = s < 4 ? make_uint4(f.x, f.y, f.z, f.w) : make_uint4(f.x & km0, f.y & km1, f.z & km23, f.w & km23);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    union { uint4 u; bf16x8_t v; } ua;
+                    ua.u = wf[a][s];
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[a], 0, 0, 0);
+                }
+            }
+            char* crow = (char*)conv_s + q * 128 + ((fq & 1) << 3);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float4 bq = *(const float4*)(bias_s + 16 * a + 4 * fq);
+                const float v0 = fmaxf(__fadd_rn(acc[a][0], bq.x), 0.f), v1 = fmaxf(__fadd_rn(acc[a][1], bq.y), 0.f);
+                const float v2 = fmaxf(__fadd_rn(acc[a][2], bq.z), 0.f), v3 = fmaxf(__fadd_rn(acc[a][3], bq.w), 0.f);
+                *(uint2*)(crow + (((2 * a + (fq >> 1)) ^ (q & 7)) << 4)) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + 256 * it;
+            const int u = item & 7, pp = item >> 3;
+            const int ppy = pp >> 3, ppx = pp & 7;
+            const int gpy = py0 + ppy, gpx = px0 + ppx;
+            if (gpy < p.Hp && gpx < p.Wp) {
+                const int qm = (2 * ppy + 1) * CT + 2 * ppx + 1;        // the centre tap: always inside the conv map
+                u16x2_t best[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const bool rok = (unsigned)(2 * gpy - 1 + r) < (unsigned)p.Hc;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const bool ok = rok && (unsigned)(2 * gpx - 1 + s) < (unsigned)p.Wc;
+                        const int q = ok ? qm + (r - 1) * CT + (s - 1) : qm;
+                        const uint4 v = *(const uint4*)((const char*)conv_s + q * 128 + ((u ^ (q & 7)) << 4));
+                        best[0] = __builtin_elementwise_max(best[0], __builtin_bit_cast(u16x2_t, v.x));
+                        best[1] = __builtin_elementwise_max(best[1], __builtin_bit_cast(u16x2_t, v.y));
+                        best[2] = __builtin_elementwise_max(best[2], __builtin_bit_cast(u16x2_t, v.z));
+                        best[3] = __builtin_elementwise_max(best[3], __builtin_bit_cast(u16x2_t, v.w));
+                    }
+                }
+                *(uint4*)(p.out + (((img * p.Hp + gpy) * p.Wp + gpx) << 6) + 8 * u) =
+                    make_uint4(__builtin_bit_cast(uint32_t, best[0]), __builtin_bit_cast(uint32_t, best[1]),
+                               __builtin_bit_cast(uint32_t, best[2]), __builtin_bit_cast(uint32_t, best[3]));
+            }
+        }
+        // the next tile's fill only writes strip_s (its readers are past the barrier above); conv_s is rewritten behind the
+        // next barrier, which every pool reader reaches first
+    }
+#undef FAV_STEM_REQUEST
+}
+
+// ---------------------------------------------------------------------------
 // Convolution as implicit-im2col GEMM on MFMA.
 //   Y[m, n] = sum_k A[m, k] * Wt[n, k],  m = (frame, oh, ow), k = (r, s, c)
 // NHWC activations make every 64-wide K tile one contiguous 128-B run of one

@@ -151,7 +151,7 @@ typedef struct fav_profile {
 } fav_profile;
 /* One row per op of the static schedule (valid after fav_get_profile). */
 typedef struct fav_op_profile {
-    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout, 5 fused bottleneck tail, 6 entry dropout + reduce */
+    int32_t op_index, kind;          /* kind: 0 stem im2col, 1 conv/fc, 2 maxpool, 3 avgpool, 4 entry dropout, 5 fused bottleneck tail, 6 entry dropout + reduce, 7 fused stem (conv + max pool) */
     int32_t H, W, Cin, Ho, Wo, Cout, kh, kw, stride;
     int32_t reserved;
     double ms, flops, bytes;
@@ -206,6 +206,11 @@ fav_status fav_op_bottleneck_tail(const fav_tail_desc* d, void* hip_stream);
 fav_status fav_op_stem_im2col(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W,
                               int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t kpad,
                               const float* mean3, const float* inv_std3, void* out, void* hip_stream);
+/* the ImageNet stem in one launch: frames (u8 or fp32 NHWC3) -> normalise -> 7x7/2 conv to 64 channels (w [64][192] bf16,
+ * k = (r*7 + s)*3 + c, zero for k >= 147) -> + bias -> ReLU -> bf16 -> 3x3/2 max pool -> out [n][Hp][Wp][64] bf16;
+ * bit-identical to fav_op_stem_im2col + fav_op_conv2d + fav_op_maxpool3x3s2 */
+fav_status fav_op_stem_pool(const void* images, int32_t layout, int32_t n, int32_t H, int32_t W, const void* w, const float* bias,
+                            const float* mean3, const float* inv_std3, void* out, void* hip_stream);
 fav_status fav_op_maxpool3x3s2(const void* x, void* y, int32_t n, int32_t H, int32_t W, int32_t C, void* hip_stream);
 fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t C,
                           const fav_dropout_desc* drop, void* hip_stream);

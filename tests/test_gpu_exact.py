@@ -197,3 +197,34 @@ def test_resnet50_wide_frames_mix_fused_tails_and_fallbacks(r50_blob):
     cfg = O.ClassifyConfig(n_samples=2, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact="mfma")
     ref = O.classify(model, frames, cfg, img_ids=np.arange(5, 7), return_logits=True)[2]
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("n,H,W", [(2, 224, 224), (3, 64, 80), (1, 33, 47), (1, 240, 320), (5, 9, 7)])
+def test_stem_pool_fused_bitwise(lib, layout, n, H, W):
+    """The ImageNet stem as ONE launch (stem7_pool_kernel: normalise, 7x7/2 convolution gathered from an LDS patch, bias,
+    ReLU, 3x3/2 max pool) against the oracle's normalise -> im2col -> MFMA-model GEMM -> epilogue -> max pool: same
+    bits for both frame layouts, frame sizes that are no multiple of the 8 x 8 pool tile, and frames smaller than a tile."""
+    import ctypes as C
+    rng = np.random.default_rng(H * 1000 + W + n)
+    img = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8) if layout == 0 else rng.random((n, H, W, 3), dtype=np.float32)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    istd = O.inv_std32(std)
+    w = O.bf16_round((rng.standard_normal((64, 7, 7, 3)) * np.sqrt(2.0 / 147)).astype(np.float32))
+    b = (rng.standard_normal(64) * 0.2).astype(np.float32)
+    cols, ho, wo = O._im2col(O.normalize_input(img, mean, istd), 7, 7, 2, 3)
+    a = np.zeros((n, ho, wo, 192), np.float32)
+    a[..., :147] = cols.reshape(n, ho, wo, 147)
+    wp = np.zeros((64, 1, 1, 192), np.float32)
+    wp[:, 0, 0, :147] = w.reshape(64, 147)
+    ref = O.maxpool3x3s2(O.epilogue(O.conv_acc_exact(a, wp, 1, 1, 1, 0, mode="mfma"), b, res=None, relu=True))
+    out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    m3 = (C.c_float * 3)(*mean)
+    i3 = (C.c_float * 3)(*[float(v) for v in istd])
+    wd = torch.from_numpy(wp.reshape(64, 192)).cuda().to(torch.bfloat16).contiguous()
+    bd = torch.from_numpy(b).cuda()
+    _lib.check(lib.fav_op_stem_pool(torch.from_numpy(img).cuda().data_ptr(), layout, n, H, W, wd.data_ptr(), bd.data_ptr(), m3, i3,
+                                    out.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = out.to(torch.float32).cpu().numpy()
+    assert np.array_equal(got, ref), f"{np.mean(got != ref):.5f} of elements differ"

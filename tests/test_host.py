@@ -359,6 +359,8 @@ def _replay(ops):
             wr(o["out"], ("avgpool", x, o["site"]))
         elif k == 4:
             wr(o["out"], ("entry_dropout", o["site"], x))
+        elif k == 7:                  # the fused ImageNet stem: im2col + GEMM + max pool in one launch
+            wr(o["out"], ("maxpool", ("conv", o["layer"], ("im2col", x), None, 1, -1)))
         elif k == 6:                  # entry dropout + the 1x1 reduce behind it
             y = ("entry_dropout", o["site"], x)
             wr(o["out"], y)

@@ -29,7 +29,7 @@ for _ in range(a.steps):
 e1.record(); torch.cuda.synchronize()
 cls = be.get_profile()
 rows = be.get_op_profile()
-kinds = ["im2col", "conv", "maxpool", "avgpool", "dropout", "tail", "drop+red"]
+kinds = ["im2col", "conv", "maxpool", "avgpool", "dropout", "tail", "drop+red", "stem+pool"]
 tot = sum(r["ms"] for r in rows)
 print(f"wall {e0.elapsed_time(e1)/a.steps:.2f} ms/step, sum of kernel ms {tot/a.steps:.2f}, policy {a.policy} T={T} batch {a.batch}")
 print(f"{'op':>3} {'kind':8} {'in':>16} {'out':>14} {'k':>3} {'s':>2} {'launch':>6} {'ms/step':>8} {'%':>5} {'TF/s':>7} {'GB/s':>7}")
