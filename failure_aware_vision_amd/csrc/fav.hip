@@ -76,8 +76,10 @@ struct Layer {  // one convolution / fc
     int cout_pad, k;         // device layout: w[cout_pad][k], bias[cout_pad]
     uint16_t* w = nullptr;          // weights / bias of the member being run
     float* b = nullptr;
-    std::vector<uint16_t*> w_m;     // per ensemble member
-    std::vector<float*> b_m;
+    std::vector<uint16_t*> w_m;     // per ensemble member: w_slab + member * w_stride (one allocation, so that a grouped
+    std::vector<float*> b_m;        // launch reaches member g's weights at a constant stride)
+    void *w_slab = nullptr, *b_slab = nullptr;
+    size_t w_stride = 0, b_stride = 0;
 };
 
 enum OpKind { OP_STEM_IM2COL, OP_CONV, OP_MAXPOOL, OP_AVGPOOL, OP_ENTRY_DROPOUT, OP_TAIL, OP_ENTRY_REDUCE, OP_STEM_POOL };
@@ -139,6 +141,13 @@ struct fav_handle {
                       hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     std::vector<MemberWs> mws;
     hipEvent_t ev_members = nullptr;
+    // Grouped launches (FAV_ENS_GROUPED, default: calls of up to FAV_ENS_GROUPED_MAX frames, see classify_on_stream): every op of
+    // the schedule is ONE launch over all members - block row blockIdx.y is member y, whose tensors lie at a constant byte
+    // stride behind member 0's (the workspaces and the weights are slabs).  `grp` is what the launchers add to a launch.
+    struct Group { int n = 1; long long x = 0, w = 0, b = 0, res = 0, y = 0, wb = 0, bb = 0, wa = 0, ba = 0, y2 = 0; };
+    Group grp;
+    bool can_group = false;
+    int group_max_frames = 0;
     std::vector<hipStream_t> vit_streams;   // ViT: parts of the batch side by side
     std::vector<hipEvent_t> vit_done;
     bool plan_no_fuse = false;      // fav_plan_schedule: build the layer-by-layer schedule (the fused one's reference)
@@ -289,7 +298,8 @@ bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
         d.out_f32 || d.relu != 0 || d.math_mode != FAV_MATH_BF16 || (d.stride != 1 && d.stride != 2)) return false;
     const int Ho = conv_out(d.H, 1, d.stride, 0), Wo = conv_out(d.W, 1, d.stride, 0);
     const long long M = (long long)d.n_frames * Ho * Wo;
-    if (M < (wide ? 512 * 256 : 4096) || M > 0x7fffffffLL || (long long)d.H * d.W * d.Cin * 2 * 4 >= 0x40000000LL) return false;
+    const int groups = h ? h->grp.n : 1;               // a grouped launch is as large as all its members together
+    if (M * groups < (wide ? 512 * 256 : 4096) || M > 0x7fffffffLL || (long long)d.H * d.W * d.Cin * 2 * 4 >= 0x40000000LL) return false;
     TailParams p;
     memset(&p, 0, sizeof p);
     p.t1 = (const uint16_t*)d.x; p.wc = (const uint16_t*)d.w; p.bias_c = d.bias; p.y = (uint16_t*)d.y;
@@ -300,6 +310,8 @@ bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
     p.div_hw = fastdiv_make((uint32_t)p.HW);
     p.div_w = fastdiv_make((uint32_t)Wo);
     p.dbg = nullptr;
+    const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
+    p.g_t1 = G.x; p.g_wc = G.w; p.g_bc = G.b; p.g_y = G.y;
     const int lds = 2 * 64 * d.Cin * 2 + (d.Cin + d.Cout) * 5 + 16;
     auto kern = bottleneck_tail_kernel<256, 0, false, 2, 4, true, 32, 512, false, false>;
     auto kern_w = bottleneck_tail_kernel<512, 0, false, 2, 8, true, 32, 1024, false, false>;
@@ -309,11 +321,11 @@ bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
             hipFuncSetAttribute((const void*)kern_w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set.set_current();
     }
-    const double flops = 2.0 * (double)M * d.Cin * d.Cout;
-    const double bytes = 2.0 * ((double)M * (d.Cin + d.Cout) + (double)d.Cin * d.Cout);
+    const double flops = 2.0 * (double)M * d.Cin * d.Cout * G.n;
+    const double bytes = 2.0 * ((double)M * (d.Cin + d.Cout) + (double)d.Cin * d.Cout) * G.n;
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
-    if (wide) hipLaunchKernelGGL(kern_w, dim3((unsigned)((M + 255) / 256)), dim3(512), lds, s, p, 0);
-    else hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), lds, s, p, 0);
+    if (wide) hipLaunchKernelGGL(kern_w, dim3((unsigned)((M + 255) / 256), G.n), dim3(512), lds, s, p, 0);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128), G.n), dim3(256), lds, s, p, 0);
     return true;
 }
 
@@ -344,6 +356,8 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     p.div_w = fastdiv_make((uint32_t)p.Wo);
     if (p.drop.site >= 0 && (p.drop.v0 < 0 || p.drop.v0 + d.n_frames > 0x7fffffffLL)) return "conv: virtual frame index out of range";
     p.dbg = nullptr;
+    const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
+    p.g_x = G.x; p.g_w = G.w; p.g_bias = G.b; p.g_res = G.res; p.g_y = G.y;
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
     // the ViT encoder's GEMMs (M = 197 rows per frame, K = 768 / 3072, 64 frames per call): measured on MI355X
     // (profiles/r2g_vit_knobs.txt) 128-row tiles with 32-deep steps at three blocks per CU beat the 256 x 256 tile (the GELU
@@ -352,7 +366,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     // ViT: the 256 x 256 tile only for launches with >= FAV_VIT_BIG_TILES of them (default: never at the per-GPU share of 64 frames, see below)
     static const long long vit_big_tiles = [] { const char* e = getenv("FAV_VIT_BIG_TILES"); return e ? atoll(e) : 512ll; }();
     const bool vit_big = vit && (M / 256) * (cout_pad / 256) >= vit_big_tiles;
-    const bool big = (!vit || vit_big) && conv_big(d.kh, d.kw, M, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
+    const bool big = (!vit || vit_big) && conv_big(d.kh, d.kw, M * G.n, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
     const int BK = big ? 64 : (vit ? 32 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr));
     const int BM = big ? 256 : conv_bm(d.kh, d.kw, M);
@@ -369,9 +383,9 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     p.tiles_n = cout_pad / BN;
     const long long tiles = (long long)p.tiles_m * p.tiles_n;
     if (tiles > 0x7fffffffLL) return "conv: too many tiles";
-    const double flops = 2.0 * (double)M * d.Cout * p.K;
+    const double flops = 2.0 * (double)M * d.Cout * p.K * G.n;
     const double bytes = 2.0 * ((double)d.n_frames * d.H * d.W * d.Cin + (double)M * d.Cout * (d.res ? 2 : 1) * (d.out_f32 ? 2 : 1)
-                                + (double)d.Cout * p.K);
+                                + (double)d.Cout * p.K) * G.n;
     static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
     if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)tiles * 32); (void)hipMemset(p.dbg, 0, (size_t)tiles * 32); }
     auto dbg_report = [&](long long nblocks, int bm, int bn, int bk) {
@@ -396,7 +410,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     // per 256 output pixels instead of once per tap (conv3x3_halo_kernel).  FAV_CONV_HALO=0 disables.
     static const int halo_mode = [] { const char* e = getenv("FAV_CONV_HALO"); return e ? atoi(e) : 1; }();
     if (halo_mode && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 && !d.res && p.drop.site < 0 && !d.out_f32 &&
-        (d.Cin == 64 || d.Cin == 128) && d.Cout == cout_pad && d.Cout == d.Cin && M >= 2048) {
+        (d.Cin == 64 || d.Cin == 128) && d.Cout == cout_pad && d.Cout == d.Cin && M * G.n >= 2048) {
         // Cin 64: 512-pixel tiles, all 9 K tiles of the weights resident; Cin 128: 256-pixel tiles, weights double-buffered per tap
         // 256-pixel tiles, 8 waves (measured best on both shapes); FAV_HALO_CFG=0 selects 128-pixel tiles with 4 waves and
         // several blocks per CU for experiments
@@ -407,7 +421,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
         const int lds = patch_bytes + wstages * d.Cout * 128 + d.Cout * 5 + 512;   // + 256 zero bytes on a 256-byte boundary
         if (lds <= 160 * 1024) {
             p.nk = 9 * d.Cin / 64;
-            dim3 hgrid((unsigned)((p.M + HBM - 1) / HBM));
+            dim3 hgrid((unsigned)((p.M + HBM - 1) / HBM), G.n);
 #define FAV_HALO(KERNEL_)                                                                                            \
     do {                                                                                                             \
         static DeviceFlags attr_set;   /* hipFuncSetAttribute applies to the CURRENT device only */                  \
@@ -433,7 +447,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
             return nullptr;
         }
     }
-    dim3 grid((unsigned)tiles);
+    dim3 grid((unsigned)tiles, G.n);
     p.nk = p.K / BK;
     // FAV_CONV_EPI=0 selects the round-1 epilogue (fp32 staging through LDS) for A/B measurements
     // measured (profiles/r2b_conv_epilogue_ab.txt): the register epilogue wins 2-4 % on the 3x3 and K >= 512 launches
@@ -563,14 +577,17 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     p.div_hw = fastdiv_make((uint32_t)p.HW);
     p.div_w = fastdiv_make((uint32_t)d.W);
     if (p.drop.site >= 0 && (p.drop.v0 < 0 || p.drop.v0 + d.n_frames > 0x7fffffffLL)) return "bottleneck tail: virtual frame index out of range";
+    const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
+    p.g_t1 = G.x; p.g_res = G.res; p.g_y = G.y; p.g_t1n = G.y2;
+    p.g_wb = G.wb; p.g_bb = G.bb; p.g_wc = G.w; p.g_bc = G.b; p.g_wa = G.wa; p.g_ba = G.ba;
     const int cmid = d.Cmid, cout = 4 * cmid;
-    const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
-    const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred);
+    const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
+    const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
     { static const int lds_pad = [] { const char* e = getenv("FAV_TAIL_LDS_PAD"); return e ? atoi(e) : 0; }(); if (g.lds_bytes + lds_pad <= 160 * 1024) g.lds_bytes += lds_pad; }   // experiments: fewer blocks per CU
     const int bm = g.rp * g.nw;
     const long long nblocks = (M + bm - 1) / bm;
-    dim3 grid((unsigned)nblocks);
+    dim3 grid((unsigned)nblocks, G.n);
     p.dbg = nullptr;
     static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
     if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)nblocks * 128); (void)hipMemset(p.dbg, 0, (size_t)nblocks * 128); }
@@ -705,13 +722,15 @@ const char* launch_stem_pool(fav_handle* h, const void* images, int layout, int 
     p.tiles_y = (p.Hp + 7) / 8; p.tiles_x = (p.Wp + 7) / 8;
     p.tiles = (long long)n * p.tiles_y * p.tiles_x;
     p.m0 = mean[0]; p.m1 = mean[1]; p.m2 = mean[2]; p.i0 = istd[0]; p.i1 = istd[1]; p.i2 = istd[2];
+    const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
+    p.g_w = G.w; p.g_bias = G.b; p.g_out = G.y;
     const double M = (double)n * p.Hc * p.Wc;
-    Prof pr(h, s, FAV_K_CONV, 2.0 * M * 64 * 192,
-            (double)n * H * W * 3 * (layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4) + 2.0 * n * p.Hp * p.Wp * 64 + 2.0 * 64 * 192);
-    // two blocks per CU (226 VGPRs, 48 KB of LDS); blocks loop over the tiles with the weights in registers
-    const unsigned blocks = (unsigned)std::min<long long>(p.tiles, 256 * 2);
-    if (layout == FAV_LAYOUT_NHWC_U8) hipLaunchKernelGGL(stem7_pool_kernel<0>, dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(stem7_pool_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    Prof pr(h, s, FAV_K_CONV, 2.0 * M * 64 * 192 * G.n,
+            ((double)n * H * W * 3 * (layout == FAV_LAYOUT_NHWC_U8 ? 1 : 4) + 2.0 * n * p.Hp * p.Wp * 64 + 2.0 * 64 * 192) * G.n);
+    // two blocks per CU (232 VGPRs, 66 KB of LDS); blocks loop over the tiles with the weights in registers
+    const unsigned blocks = (unsigned)std::min<long long>(p.tiles, std::max(1, 256 * 2 / G.n));
+    if (layout == FAV_LAYOUT_NHWC_U8) hipLaunchKernelGGL(stem7_pool_kernel<0>, dim3(blocks, G.n), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(stem7_pool_kernel<1>, dim3(blocks, G.n), dim3(256), 0, s, p);
     return nullptr;
 }
 
@@ -719,8 +738,9 @@ void launch_avgpool(fav_handle* h, const void* x, void* y, int n, int HW, int C,
     const long long total = (long long)n * (C / 16);
     Prof pr(h, s, FAV_K_AVGPOOL, 0.0, 2.0 * ((double)n * HW * C + (double)n * C));
     const float inv = 1.0f / (float)HW;
-    hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)x, (uint4*)y, n, HW, C, inv,
-                       dp);
+    const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
+    hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total), G.n), dim3(256), 0, s, (const uint4*)x, (uint4*)y, n, HW, C, inv,
+                       dp, G.x, G.y);
 }
 
 void launch_entry_dropout(fav_handle* h, const void* x, void* out, long long elems, int n_out, const DropParams& dp,
@@ -927,7 +947,10 @@ fav_status build_graph(fav_handle* h) {
                 TailGeom tg;
                 // the 256-pixel / 8-wave kernels of layers 3-4 run one block per CU: they pay only when the planned launch
                 // (max_batch frames, x T samples behind the first dropout site) brings two blocks per CU
-                const long long plan_rows = (long long)c.max_batch * ((mc_first_site >= 0 && bidx > mc_first_site) ? c.n_samples : 1) * Hn * Wn;
+                // (an ensemble without MC-Dropout runs every op as one launch over its members, see classify_on_stream)
+                const char* grp_env = getenv("FAV_ENS_GROUPED");
+                const int plan_groups = (h->n_members > 1 && mc_first_site < 0 && !(grp_env && atoi(grp_env) == 0)) ? h->n_members : 1;
+                const long long plan_rows = (long long)c.max_batch * ((mc_first_site >= 0 && bidx > mc_first_site) ? c.n_samples : 1) * Hn * Wn * plan_groups;
                 const char* min_rows_env = getenv("FAV_TAIL_MIN_ROWS");        // tests: 0 forces those kernels at any size
                 const bool big_launch = plan_rows >= (min_rows_env ? atoll(min_rows_env) : 512ll * 256);
                 const bool tail_3x3 = (s == 1) && (pl <= 128 || (pl == 256 && tail_wide3x3() && big_launch));
@@ -1154,7 +1177,12 @@ fav_status plan_memory(fav_handle* h) {
     }
     act_bytes = (act_bytes + 255) / 256 * 256 + 256;
     a1_bytes = (a1_bytes + 255) / 256 * 256 + 256;
-    for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&h->act[i], act_bytes));
+    // deep ensemble with its members side by side: every workspace tensor is a slab of n_members equal parts (member 0's part
+    // is the handle's own buffer), so that a grouped launch finds member g's tensors at a constant stride
+    static const int ens_streams = [] { const char* e = getenv("FAV_ENS_STREAMS"); return e ? atoi(e) : 1; }();
+    const bool side_by_side = h->n_members > 1 && ens_streams && h->pipe_first < 0;
+    const size_t parts = side_by_side ? (size_t)h->n_members : 1;
+    for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&h->act[i], act_bytes * parts));
     h->act_bytes = act_bytes;
     if (h->pipe_first >= 0) {
         act2_bytes = (act2_bytes + 255) / 256 * 256 + 256;
@@ -1166,18 +1194,19 @@ fav_status plan_memory(fav_handle* h) {
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join_a, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join_b, hipEventDisableTiming));
     }
-    HIP_TRY(h, hipMalloc(&h->a1, a1_bytes));
+    HIP_TRY(h, hipMalloc(&h->a1, a1_bytes * parts));
     h->a1_bytes = a1_bytes;
     h->phase_out.assign(h->phases.size(), nullptr);
+    std::vector<size_t> phase_bytes(h->phases.size(), 0);
     for (size_t i = 0; i + 1 < h->phases.size(); ++i) {
         const Phase& p = h->phases[i];
         const long long dom = p.suffix ? nv_max : c.max_batch;
-        HIP_TRY(h, hipMalloc(&h->phase_out[i], (size_t)dom * p.out_elems * p.out_bytes_per_elem + 256));
+        phase_bytes[i] = ((size_t)dom * p.out_elems * p.out_bytes_per_elem + 255) / 256 * 256 + 256;
+        HIP_TRY(h, hipMalloc(&h->phase_out[i], phase_bytes[i] * parts));
     }
     HIP_TRY(h, hipMalloc((void**)&h->logits, (size_t)nv_max * h->n_members * h->cpad * 4 + 256));
     h->phase_out.back() = h->logits;
-    static const int ens_streams = [] { const char* e = getenv("FAV_ENS_STREAMS"); return e ? atoi(e) : 1; }();
-    if (h->n_members > 1 && ens_streams && h->pipe_first < 0) {
+    if (side_by_side) {
         h->mws.resize(h->n_members);
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_members, hipEventDisableTiming));
         for (int m = 0; m < h->n_members; ++m) {
@@ -1185,20 +1214,17 @@ fav_status plan_memory(fav_handle* h) {
             HIP_TRY(h, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
             HIP_TRY(h, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
             w.phase_out.assign(h->phases.size(), nullptr);
-            if (m == 0) {
-                for (int i = 0; i < 5; ++i) w.act[i] = h->act[i];
-                w.a1 = h->a1;
-                for (size_t i = 0; i + 1 < h->phases.size(); ++i) w.phase_out[i] = h->phase_out[i];
-                continue;
-            }
-            for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&w.act[i], act_bytes));
-            HIP_TRY(h, hipMalloc(&w.a1, a1_bytes));
-            for (size_t i = 0; i + 1 < h->phases.size(); ++i) {
-                const Phase& p = h->phases[i];
-                const long long dom = p.suffix ? nv_max : c.max_batch;
-                HIP_TRY(h, hipMalloc(&w.phase_out[i], (size_t)dom * p.out_elems * p.out_bytes_per_elem + 256));
-            }
+            for (int i = 0; i < 5; ++i) w.act[i] = (char*)h->act[i] + (size_t)m * act_bytes;
+            w.a1 = (char*)h->a1 + (size_t)m * a1_bytes;
+            for (size_t i = 0; i + 1 < h->phases.size(); ++i) w.phase_out[i] = (char*)h->phase_out[i] + (size_t)m * phase_bytes[i];
         }
+        // grouped launches: every op must be one the grouped kernels cover (no MC-Dropout suffix, fused stem)
+        h->can_group = h->T_eff == 1 && c.math_mode == FAV_MATH_BF16;
+        for (const Op& o : h->ops)
+            if (o.kind != OP_STEM_POOL && o.kind != OP_CONV && o.kind != OP_TAIL && o.kind != OP_AVGPOOL) h->can_group = false;
+        for (const Op& o : h->ops) if (o.site >= 0) h->can_group = false;
+        const char* ge = getenv("FAV_ENS_GROUPED");           // 0: never; N > 0: only calls of up to N frames (default: every call)
+        h->group_max_frames = ge ? atoi(ge) : 0x7fffffff;
     }
     return FAV_OK;
 }
@@ -1208,7 +1234,7 @@ fav_status plan_memory(fav_handle* h) {
 // launches to these ops of the phase (-1: all) - the ensemble enqueues op by op across its members' streams
 fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, int n, long long first_index,
                       hipStream_t s, long long v_begin, long long v_end, void** act_set, const fav_handle::MemberWs* ws = nullptr,
-                      int member = -1, int k_lo = -1, int k_hi = -1) {
+                      int member = -1, int k_lo = -1, int k_hi = -1, int group_n = 1) {
     const fav_config& c = h->cfg;
     const Phase& p = h->phases[pi];
     auto LW = [&](int li) -> void* { return member >= 0 ? h->layers[li].w_m[member] : h->layers[li].w; };
@@ -1241,9 +1267,32 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                 default: return act_set[id];
             }
         };
+        // grouped launch (ws = member 0's workspace): byte stride from member 0's tensor to member 1's, per buffer and per layer
+        auto gbuf = [&](int id) -> long long {
+            if (group_n <= 1) return 0;
+            const fav_handle::MemberWs &w0 = h->mws[0], &w1 = h->mws[1];
+            switch (id) {
+                case B_INPUT: case B_NONE: return 0;
+                case B_PHASE_IN: return pi == 0 ? 0 : (char*)w1.phase_out[pi - 1] - (char*)w0.phase_out[pi - 1];
+                case B_PHASE_OUT: return (char*)w1.phase_out[pi] - (char*)w0.phase_out[pi];
+                case B_A1: return (char*)w1.a1 - (char*)w0.a1;
+                default: return (char*)w1.act[id] - (char*)w0.act[id];
+            }
+        };
+        auto gw = [&](int li) -> long long { return group_n > 1 && li >= 0 ? (long long)h->layers[li].w_stride : 0; };
+        auto gb = [&](int li) -> long long { return group_n > 1 && li >= 0 ? (long long)h->layers[li].b_stride : 0; };
+        struct GroupReset { fav_handle* h; ~GroupReset() { h->grp = fav_handle::Group{}; } } group_reset{h};
         for (int k = op_lo; k < op_hi; ++k) {
             const Op& o = h->ops[k];
             h->cur_op = k;
+            if (group_n > 1) {
+                fav_handle::Group G;
+                G.n = group_n;
+                G.x = gbuf(o.in); G.res = gbuf(o.res); G.y = gbuf(o.out); G.y2 = gbuf(o.out2);
+                if (o.kind == OP_TAIL) { G.w = gw(o.layer_c); G.b = gb(o.layer_c); G.wb = gw(o.layer); G.bb = gb(o.layer); G.wa = gw(o.layer_a); G.ba = gb(o.layer_a); }
+                else { G.w = gw(o.layer); G.b = gb(o.layer); }
+                h->grp = G;
+            }
             fav_dropout_desc dd;
             dd.site = o.site; dd.threshold = thr; dd.scale = scale; dd.seed = c.seed;
             dd.v0 = p.suffix ? v0 : 0; dd.n_img = n; dd.first_image_index = first_index;
@@ -1314,8 +1363,9 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
 
 void free_all(fav_handle* h) {
     for (auto& L : h->layers) {
-        for (auto pw : L.w_m) if (pw) (void)hipFree(pw);
-        for (auto pb : L.b_m) if (pb) (void)hipFree(pb);
+        if (L.w_slab) (void)hipFree(L.w_slab);
+        if (L.b_slab) (void)hipFree(L.b_slab);
+        L.w_slab = L.b_slab = nullptr;
         L.w_m.clear(); L.b_m.clear(); L.w = nullptr; L.b = nullptr;
     }
     for (int i = 0; i < 5; ++i) if (h->act[i]) (void)hipFree(h->act[i]);
@@ -1329,11 +1379,6 @@ void free_all(fav_handle* h) {
     if (h->a1) (void)hipFree(h->a1);
     for (size_t m = 0; m < h->mws.size(); ++m) {
         fav_handle::MemberWs& w = h->mws[m];
-        if (m > 0) {
-            for (int i = 0; i < 5; ++i) if (w.act[i]) (void)hipFree(w.act[i]);
-            if (w.a1) (void)hipFree(w.a1);
-            for (size_t i = 0; i + 1 < w.phase_out.size(); ++i) if (w.phase_out[i]) (void)hipFree(w.phase_out[i]);
-        }
         if (w.stream) (void)hipStreamDestroy(w.stream);
         if (w.done) (void)hipEventDestroy(w.done);
     }
@@ -1596,6 +1641,24 @@ fav_status fav_check_blob(const void* blob, size_t size, char* err, size_t err_c
     return FAV_OK;
 }
 
+namespace {
+// one allocation per layer for the weights of all members (and one for the biases): member m at slab + m * stride
+fav_status alloc_layer_slabs(fav_handle* h, Layer& L, size_t wbytes, size_t bbytes) {
+    if (L.w_slab) return FAV_OK;
+    L.w_stride = (wbytes + 255) / 256 * 256;
+    L.b_stride = (bbytes + 255) / 256 * 256;
+    HIP_TRY(h, hipMalloc(&L.w_slab, L.w_stride * h->n_members));
+    HIP_TRY(h, hipMalloc(&L.b_slab, L.b_stride * h->n_members));
+    L.w_m.assign(h->n_members, nullptr);
+    L.b_m.assign(h->n_members, nullptr);
+    for (int m = 0; m < h->n_members; ++m) {
+        L.w_m[m] = (uint16_t*)((char*)L.w_slab + (size_t)m * L.w_stride);
+        L.b_m[m] = (float*)((char*)L.b_slab + (size_t)m * L.b_stride);
+    }
+    return FAV_OK;
+}
+}  // namespace
+
 fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* blob, size_t size) {
     if (!h) return FAV_ERR_INVALID_ARG;
     if (member < 0 || member >= h->n_members) { h->err = fmt("fav_load_member_weights: member %d outside [0, %d)", member, h->n_members); return FAV_ERR_INVALID_ARG; }
@@ -1628,10 +1691,7 @@ fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* bl
         if (L.kh == 0) {   // a pair of fp32 vectors (LayerNorm gamma / beta, ViT position table)
             const size_t vb = (size_t)L.cout * 4;
             // (ranges and alignment already validated by fav_check_blob against these very table entries)
-            L.w_m.resize(h->n_members, nullptr);
-            L.b_m.resize(h->n_members, nullptr);
-            if (!L.w_m[member]) HIP_TRY(h, hipMalloc((void**)&L.w_m[member], vb));
-            if (!L.b_m[member]) HIP_TRY(h, hipMalloc((void**)&L.b_m[member], vb));
+            if (fav_status st = alloc_layer_slabs(h, L, vb, vb)) return st;
             HIP_TRY(h, hipMemcpy(L.w_m[member], p + off[0], vb, hipMemcpyHostToDevice));
             HIP_TRY(h, hipMemcpy(L.b_m[member], p + off[1], vb, hipMemcpyHostToDevice));
             continue;
@@ -1645,10 +1705,7 @@ fav_status fav_load_member_weights(fav_handle* h, int32_t member, const void* bl
         for (int n = 0; n < L.cout; ++n) memcpy(&wtmp[(size_t)n * L.k], src + (size_t)n * kreal, kreal * 2);
         btmp.assign(L.cout_pad, 0.f);
         memcpy(btmp.data(), p + off[1], bbytes);
-        L.w_m.resize(h->n_members, nullptr);
-        L.b_m.resize(h->n_members, nullptr);
-        if (!L.w_m[member]) HIP_TRY(h, hipMalloc((void**)&L.w_m[member], wtmp.size() * 2));
-        if (!L.b_m[member]) HIP_TRY(h, hipMalloc((void**)&L.b_m[member], btmp.size() * 4));
+        if (fav_status st = alloc_layer_slabs(h, L, wtmp.size() * 2, btmp.size() * 4)) return st;
         HIP_TRY(h, hipMemcpy(L.w_m[member], wtmp.data(), wtmp.size() * 2, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(L.b_m[member], btmp.data(), btmp.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1733,6 +1790,16 @@ fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int3
             if (st != FAV_OK) return st;
         } else {
             fav_status st = run_vit(h, images, layout, 0, n, s);
+            if (st != FAV_OK) return st;
+        }
+    } else if (!h->mws.empty() && h->can_group && n <= h->group_max_frames) {
+        // small calls: every op ONE launch over all members (block row = member), on the caller's stream.  At the 8-GPU share
+        // of configs[3] (32 frames) a member's launches are a few dozen tiles each; five of them in one grid fill the chip
+        // where five streams only interleave (profiles/r3aa_ens_grouped_ab.txt)
+        for (int member = 0; member < h->n_members; ++member)
+            h->mws[member].phase_out.back() = (char*)h->logits + (size_t)member * n * h->cpad * 4;
+        for (size_t pi = 0; pi < h->phases.size(); ++pi) {
+            fav_status st = run_chunks(h, pi, images, layout, n, first_index, s, 0, n, h->mws[0].act, &h->mws[0], 0, -1, -1, h->n_members);
             if (st != FAV_OK) return st;
         }
     } else if (!h->mws.empty()) {

@@ -252,6 +252,7 @@ struct StemPoolParams {
     int tiles_y, tiles_x;
     long long tiles;         // n * tiles_y * tiles_x
     float m0, m1, m2, i0, i1, i2;
+    long long g_w, g_bias, g_out;   // grouped launch: byte strides per member (blockIdx.y); the frames are shared
 };
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
@@ -259,6 +260,9 @@ struct __attribute__((aligned(4))) StemFrag { uint32_t x, y, z, w; };     // a 1
 
 template <int LAYOUT>
 __global__ __launch_bounds__(256, 2) void stem7_pool_kernel(StemPoolParams p) {
+    p.w = (const uint16_t*)((const char*)p.w + (long long)blockIdx.y * p.g_w);
+    p.bias = (const float*)((const char*)p.bias + (long long)blockIdx.y * p.g_bias);
+    p.out = (uint16_t*)((char*)p.out + (long long)blockIdx.y * p.g_out);
     constexpr int PT = 8, CT = 2 * PT + 1, NPIX = CT * CT, NGRP = (NPIX + 15) / 16;
     constexpr int PROWS = 2 * CT + 5, PVALS = PROWS * 3;          // 39 patch rows of 39 pixels = 117 values
     constexpr int SPITCH = PROWS * 21 + 1;                        // 820 elements per strip: every window 4-byte aligned
@@ -462,7 +466,22 @@ struct ConvParams {
     FastDiv div_hwo;  // / HWo
     FastDiv div_w;    // / Wo (the staged 3x3 kernel)
     unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
+    // grouped launch (the members of a deep ensemble in one launch): block row blockIdx.y works on the tensors
+    // g_* BYTES behind these, per member (0: shared by all members)
+    long long g_x, g_w, g_bias, g_res, g_y;
 };
+
+// the parameters of group member blockIdx.y
+__device__ __forceinline__ ConvParams conv_group_params(const ConvParams& q) {
+    ConvParams p = q;
+    const long long g = blockIdx.y;
+    p.x = (const uint16_t*)((const char*)q.x + g * q.g_x);
+    p.w = (const uint16_t*)((const char*)q.w + g * q.g_w);
+    p.bias = (const float*)((const char*)q.bias + g * q.g_bias);
+    if (q.res) p.res = (const uint16_t*)((const char*)q.res + g * q.g_res);
+    p.y = (void*)((char*)q.y + g * q.g_y);
+    return p;
+}
 
 // LDS swizzle of a staged K tile: rows are BK*2 bytes, a row holds BK/8 16-B chunks.
 // Physical chunk = logical chunk ^ swz(row), chosen so the four 16-lane groups a
@@ -493,7 +512,8 @@ constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
 // barrier.  (Tiles with 32 columns per wave use 32-row groups and 8 channels per lane.)  The sums are unchanged - an
 // output element still meets its products in ascending k.  EPI = 0 is the round-1 epilogue through an fp32 LDS stage.
 template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1, int PP = 0>
-__global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p_launch) {
+    const ConvParams p = conv_group_params(p_launch);
     constexpr int NT = (BM / 64) * WN * 64;     // threads: (BM/64) x WN waves, each a 64 x BN/WN sub-tile
     constexpr int NWAVES = NT / 64;
     constexpr int ROWB = BK * 2;                // bytes per staged row
@@ -1066,7 +1086,8 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
 // case to the generic kernel).
 // ---------------------------------------------------------------------------
 template <int CIN, int BN, int BM, int NS, int SUB, int OCC, int MODE>
-__global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvParams p, int patch_bytes) {
+__global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvParams p_launch, int patch_bytes) {
+    const ConvParams p = conv_group_params(p_launch);
     constexpr int NT = BM * 2, NWAVES = NT / 64;   // (BM/64) x 2 waves
     constexpr int ROWB = CIN * 2;               // bytes per staged input pixel
     constexpr int CPR = ROWB / 16;              // 16-B chunks per pixel (8 or 16)
@@ -1352,7 +1373,23 @@ struct TailParams {
     DropParams drop;
     FastDiv div_hw, div_w;
     unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
+    // grouped launch (see ConvParams): byte strides per member of the activations (t1, res, y, t1n) and of each weight / bias set
+    long long g_t1, g_res, g_y, g_t1n, g_wb, g_bb, g_wc, g_bc, g_wa, g_ba;
 };
+
+__device__ __forceinline__ TailParams tail_group_params(const TailParams& q) {
+    TailParams p = q;
+    const long long g = blockIdx.y;
+    p.t1 = (const uint16_t*)((const char*)q.t1 + g * q.g_t1);
+    if (q.wb) { p.wb = (const uint16_t*)((const char*)q.wb + g * q.g_wb); p.bias_b = (const float*)((const char*)q.bias_b + g * q.g_bb); }
+    p.wc = (const uint16_t*)((const char*)q.wc + g * q.g_wc);
+    p.bias_c = (const float*)((const char*)q.bias_c + g * q.g_bc);
+    if (q.res) p.res = (const uint16_t*)((const char*)q.res + g * q.g_res);
+    p.y = (uint16_t*)((char*)q.y + g * q.g_y);
+    if (q.wa) { p.wa = (const uint16_t*)((const char*)q.wa + g * q.g_wa); p.bias_a = (const float*)((const char*)q.bias_a + g * q.g_ba); }
+    if (q.t1n) p.t1n = (uint16_t*)((char*)q.t1n + g * q.g_t1n);
+    return p;
+}
 
 // raw workgroup barrier: this wave's LDS operations retired, no vmcnt drain (stores and prefetches stay in flight)
 #define FAV_BAR()                                               \
@@ -1378,7 +1415,8 @@ __device__ __forceinline__ int tail_sw(int row) {
 // COUT_ = 0: the bottleneck's 4*CMID.  HAS_RES / RELU = false and in_stride = 2 turn conv_c alone into the projection
 // shortcut of a stage's first block (1x1 / 2, no residual, no ReLU, no dropout).
 template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32, int COUT_ = 0, bool HAS_RES = true, bool RELU = true>
-__global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p, int patch_bytes) {
+__global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p_launch, int patch_bytes) {
+    const TailParams p = tail_group_params(p_launch);
     // Y is stored in whole 128-byte lines from an LDS image of the chunk: the one conv_a reads (NRED > 0), or - behind a staged-patch
     // conv_b, whose region A is free in P2 - an image kept for that purpose alone
     constexpr bool LINEST = NRED > 0 || (HAS3X3 && !(HAS3X3 && CMID == 256));
@@ -2020,8 +2058,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint4* __restri
 // Global average pool [n][HW][C] bf16 -> [n][C] bf16: sequential fp32 sum over
 // HW (the oracle's order), * fp32(1/HW), optional dropout, one bf16 rounding.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void avgpool_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int n,
-                                                      int HW, int C, float inv_hw, DropParams drop) {
+__global__ __launch_bounds__(256) void avgpool_kernel(const uint4* __restrict__ x_, uint4* __restrict__ y_, int n,
+                                                      int HW, int C, float inv_hw, DropParams drop, long long g_x, long long g_y) {
+    // grouped launch: member blockIdx.y reads / writes g_x / g_y bytes further on
+    const uint4* __restrict__ x = (const uint4*)((const char*)x_ + (long long)blockIdx.y * g_x);
+    uint4* __restrict__ y = (uint4*)((char*)y_ + (long long)blockIdx.y * g_y);
     const int cch = C >> 4;  // 16-channel chunks = pairs of uint4
     const long long total = (long long)n * cch;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {

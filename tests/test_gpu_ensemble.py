@@ -89,3 +89,25 @@ def test_ens5_per_gpu_share_properties(r50_members):
         assert torch.equal(single.logits()[0], lg[m]), m
         single.close()
     assert lg.shape == (5, n, 1000) and torch.isfinite(lg).all()
+
+
+@pytest.mark.parametrize("n", [5, 32, 70])
+def test_ens5_grouped_launches_equal_member_streams(r50_members, n, monkeypatch):
+    """The two ways a 5-member call runs - every op ONE launch over all members (block row = member; default for calls of
+    up to 64 frames) and one stream per member (larger calls) - give the same logits bit for bit, labels and confidences
+    included; FAV_ENS_GROUPED = frame limit of the grouped form, read when the handle is created (0: never)."""
+    x = torch.from_numpy(frames_np(300, n)).cuda()
+    blobs = [b for b, _ in r50_members]
+    out = {}
+    for limit in ("0", "4096"):
+        monkeypatch.setenv("FAV_ENS_GROUPED", limit)
+        be = Backend("resnet50", blobs, max_batch=n)
+        labels, conf = be.classify(x, first_index=300)
+        out[limit] = (labels.clone(), conf.clone(), be.logits().clone())
+        if limit == "4096":            # a second, smaller call on the same handle (strides follow the call's n)
+            l2, c2 = be.classify(x[:3], first_index=300)
+            assert torch.equal(l2, labels[:3]) and torch.equal(c2, conf[:3])
+        be.close()
+    for a, b in zip(out["0"], out["4096"]):
+        assert torch.equal(a, b)
+    assert not torch.equal(out["0"][2][0], out["0"][2][1])
