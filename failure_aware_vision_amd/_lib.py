@@ -52,7 +52,7 @@ class FavTailDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wb", C.c_void_p), ("bias_b", C.c_void_p), ("wc", C.c_void_p), ("bias_c", C.c_void_p),
                 ("res", C.c_void_p), ("y", C.c_void_p), ("wa", C.c_void_p), ("bias_a", C.c_void_p), ("t1n", C.c_void_p),
                 ("n_frames", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cmid", C.c_int32), ("Nred", C.c_int32),
-                ("drop", FavDropoutDesc)]
+                ("drop", FavDropoutDesc), ("res_entry", C.c_int32), ("entry_site", C.c_int32)]
 
 
 class FavProfile(C.Structure):

@@ -96,6 +96,8 @@ struct Op {
     int Ho = 0, Wo = 0, Co = 0;        // output dims per frame
     int relu = 0, out_f32 = 0;
     int site = -1;                     // dropout site fused into this op
+    int res_entry = 0;                 // OP_TAIL: the residual is the cached prefix output under the entry dropout (RESE)
+    int skip_y = 0;                    // OP_ENTRY_REDUCE: the dropped copies are not stored (the next tail recomputes them)
     long long in_elems = 0, out_elems = 0;  // per frame
 };
 
@@ -580,8 +582,15 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
     p.g_t1 = G.x; p.g_res = G.res; p.g_y = G.y; p.g_t1n = G.y2;
     p.g_wb = G.wb; p.g_bb = G.bb; p.g_wc = G.w; p.g_bc = G.b; p.g_wa = G.wa; p.g_ba = G.ba;
+    p.site_e = d.entry_site;
+    if (d.res_entry) {
+        if (!(d.Cmid == 64 && nred == 64 && has3x3) || p.drop.site < 0 || d.entry_site < 0 || !d.res)
+            return "bottleneck tail: res_entry needs Cmid = Nred = 64 with the 3x3 and both dropout sites";
+        if ((double)p.drop.n_img * p.HW * 4.0 * d.Cmid * 2.0 >= 2147483647.0) return "bottleneck tail: cached tensor too large for 32-bit offsets";
+    }
     const int cmid = d.Cmid, cout = 4 * cmid;
     const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
+    // res_entry: the residual is the cached tensor (read once per sample it is needed for; counted as the rows it serves, like a stored residual)
     const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
     { static const int lds_pad = [] { const char* e = getenv("FAV_TAIL_LDS_PAD"); return e ? atoi(e) : 0; }(); if (g.lds_bytes + lds_pad <= 160 * 1024) g.lds_bytes += lds_pad; }   // experiments: fewer blocks per CU
@@ -629,6 +638,21 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     } while (0)
 #define FAV_TAIL_W(CMID_, NRED_, H3_, NS_, NW_) do { if (g.wc2) FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, true); else FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, false); } while (0)
 #define FAV_TAIL_N(CMID_, NRED_, H3_, NS_) FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 4)
+    if (d.res_entry) {
+        static DeviceFlags attr_set;
+        auto k0 = bottleneck_tail_kernel<64, 64, true, 3, 4, false, 32, 0, true, true, true>;
+        auto k1 = bottleneck_tail_kernel<64, 64, true, 3, 4, true, 32, 0, true, true, true>;
+        if (!attr_set.test_current()) {
+            if (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return "bottleneck tail: cannot reserve LDS";
+            attr_set.set_current();
+        }
+        if (g.wc2) hipLaunchKernelGGL(k1, grid, dim3(256), g.lds_bytes, s, p, g.patch_bytes);
+        else hipLaunchKernelGGL(k0, grid, dim3(256), g.lds_bytes, s, p, g.patch_bytes);
+        dbg_report();
+        return nullptr;
+    }
     if (cmid == 64) {
         if (has3x3) { if (nred == 0) FAV_TAIL_N(64, 0, true, 3); if (nred == 64) FAV_TAIL_N(64, 64, true, 3); if (nred == 128) FAV_TAIL_N(64, 128, true, 3); }
         else { if (nred == 0) FAV_TAIL_N(64, 0, false, 3); if (nred == 64) FAV_TAIL_N(64, 64, false, 3); if (nred == 128) FAV_TAIL_N(64, 128, false, 3); }
@@ -771,7 +795,7 @@ const char* launch_entry_reduce(fav_handle* h, const void* x, void* y, const voi
     p.div_hw = fastdiv_make((uint32_t)HW);
     const long long cached = std::min<long long>(dp.n_img, n_out);
     const double rows = (double)n_out * HW;
-    Prof pr(h, s, FAV_K_CONV, 2.0 * rows * C * nred, 2.0 * ((double)cached * HW * C + rows * (C + nred) + (double)C * nred));
+    Prof pr(h, s, FAV_K_CONV, 2.0 * rows * C * nred, 2.0 * ((double)cached * HW * C + rows * ((y ? C : 0) + nred) + (double)C * nred));
     hipLaunchKernelGGL((entry_reduce_kernel<256, 64>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
     return nullptr;
 }
@@ -806,12 +830,12 @@ const char* launch_layernorm(fav_handle* h, const void* x, long long ldx, const 
 const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, int T, int D, int heads, int math_mode, hipStream_t s) {
     if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
     const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
-    // one wave per query tile if their P strips fit beside K and V^T (197 tokens: 13 waves, 153 KB), else 8 waves round robin
+    // one wave per query tile if their P strips fit beside K and V (197 tokens: 13 waves, 152 KB), else 8 waves round robin
     int nw = nkt > 8 ? nkt : 8;
-    if (nkt * 16 * 128 + 64 * vstride + nw * 16 * vstride > 160 * 1024) nw = 8;
+    if (nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride > 160 * 1024) nw = 8;
     static const int attn_nw = [] { const char* e = getenv("FAV_ATTN_WAVES"); return e ? atoi(e) : 0; }();   // experiments: 8 forces the old shape
     if (attn_nw == 8) nw = 8;
-    const int lds = nkt * 16 * 128 + 64 * vstride + nw * 16 * vstride;
+    const int lds = nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride;
     static DeviceFlags attr_set;
     if (!attr_set.test_current()) {
         if (hipFuncSetAttribute((const void*)attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -1082,6 +1106,24 @@ fav_status build_graph(fav_handle* h) {
                     h->ops[split] = f;
                     h->ops.erase(h->ops.begin() + split + 1);
                     if (regroup_now > split + 1) --regroup_now;
+                    // The block behind the entry: its tail can take its residual - the dropped copy of the cached prefix output -
+                    // from the cached tensor itself and apply the entry mask in its epilogue; the T copies are then neither
+                    // written (12 GB per step at the headline shape) nor read back.  FAV_ENTRY_RES=0 keeps them.
+                    static const bool entry_res = [] { const char* e = getenv("FAV_ENTRY_RES"); return !e || atoi(e) != 0; }();
+                    const int y0 = f.out;
+                    if (entry_res && split + 1 < (int)h->ops.size() && regroup_now != split + 1) {
+                        Op& tl = h->ops[split + 1];
+                        bool ok = tl.kind == OP_TAIL && tl.res == y0 && tl.in == f.out2 && tl.layer >= 0 && tl.C == 64 && tl.Co2 == 64 &&
+                                  tl.layer_a >= 0 && tl.site >= 0 && tl.out != y0 && tl.out2 != y0 &&
+                                  (double)c.max_batch * f.H * f.W * f.C * 2.0 < 2147483647.0;
+                        const int phase_end = regroup_now > split + 1 ? regroup_now : (int)h->ops.size();
+                        for (int k = split + 2; ok && k < phase_end; ++k) {     // nobody else reads the copies before their buffer is reused
+                            const Op& o = h->ops[k];
+                            if (o.in == y0 || o.res == y0) ok = false;
+                            if (o.out == y0 || o.out2 == y0) break;
+                        }
+                        if (ok) { tl.res_entry = 1; h->ops[split].skip_y = 1; }
+                    }
                 }
             }
         }
@@ -1328,6 +1370,7 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                     if (o.layer_a >= 0) { d.wa = LW(o.layer_a); d.bias_a = LB(o.layer_a); d.t1n = buf(o.out2, true, o); }
                     d.n_frames = cn; d.H = o.H; d.W = o.W; d.Cmid = o.C; d.Nred = o.Co2;
                     d.drop = dd;
+                    if (o.res_entry) { d.res = pin_base; d.res_entry = 1; d.entry_site = h->first_site; }   // the cached prefix output
                     if (const char* e = launch_tail(h, d, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
                     break;
                 }
@@ -1350,7 +1393,7 @@ fav_status run_chunks(fav_handle* h, size_t pi, const void* images, int layout, 
                 }
                 case OP_ENTRY_REDUCE: {
                     DropParams dp = make_drop(&dd);
-                    if (const char* e = launch_entry_reduce(h, pin_base, buf(o.out, true, o), LW(o.layer_a), LB(o.layer_a), buf(o.out2, true, o), o.C, o.Co2,
+                    if (const char* e = launch_entry_reduce(h, pin_base, o.skip_y ? nullptr : buf(o.out, true, o), LW(o.layer_a), LB(o.layer_a), buf(o.out2, true, o), o.C, o.Co2,
                                                             o.H * o.W, cn, dp, s)) { h->err = e; return FAV_ERR_INVALID_ARG; }
                     break;
                 }
@@ -1583,8 +1626,9 @@ fav_status fav_plan_schedule(const fav_config* cfg, int32_t flags, char* out, si
         int phase = -1;
         for (size_t pi = 0; pi < h.phases.size(); ++pi)
             if ((int)i >= h.phases[pi].op_begin && (int)i < h.phases[pi].op_end) phase = (int)pi;
-        txt += fmt("op %zu kind=%d phase=%d layer=%d lc=%d la=%d in=%d res=%d out=%d out2=%d site=%d relu=%d suffix=%d\n", i, (int)o.kind, phase, o.layer,
-                   o.layer_c, o.layer_a, o.in, o.res, o.out, o.out2, o.site, o.relu, phase >= 0 ? (int)h.phases[phase].suffix : 0);
+        txt += fmt("op %zu kind=%d phase=%d layer=%d lc=%d la=%d in=%d res=%d out=%d out2=%d site=%d relu=%d suffix=%d rese=%d skipy=%d esite=%d\n", i, (int)o.kind, phase, o.layer,
+                   o.layer_c, o.layer_a, o.in, o.res, o.out, o.out2, o.site, o.relu, phase >= 0 ? (int)h.phases[phase].suffix : 0, o.res_entry, o.skip_y,
+                   h.first_site);
     }
     if (txt.size() + 1 > cap) return FAV_ERR_INVALID_ARG;
     memcpy(out, txt.c_str(), txt.size() + 1);
@@ -2024,7 +2068,7 @@ fav_status fav_op_avgpool(const void* x, void* y, int32_t n, int32_t HW, int32_t
 
 fav_status fav_op_entry_reduce(const void* x, void* y, const void* wa, const float* bias_a, void* t1, int32_t C, int32_t Nred,
                                int32_t HW, int32_t n_out, const fav_dropout_desc* drop, void* stream) {
-    if (!x || !y || !wa || !bias_a || !t1 || !drop || drop->site < 0 || HW < 1) return op_done("fav_op_entry_reduce: bad argument");
+    if (!x || !wa || !bias_a || !t1 || !drop || drop->site < 0 || HW < 1) return op_done("fav_op_entry_reduce: bad argument");
     return op_done(launch_entry_reduce(nullptr, x, y, wa, bias_a, t1, C, Nred, HW, n_out, make_drop(drop), (hipStream_t)stream));
 }
 

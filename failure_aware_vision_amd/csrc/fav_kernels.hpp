@@ -1375,6 +1375,10 @@ struct TailParams {
     unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
     // grouped launch (see ConvParams): byte strides per member of the activations (t1, res, y, t1n) and of each weight / bias set
     long long g_t1, g_res, g_y, g_t1n, g_wb, g_bb, g_wc, g_bc, g_wa, g_ba;
+    // RESE (the first block behind the entry dropout of an MC-Dropout suffix): `res` is the CACHED prefix output
+    // [drop.n_img][HW][COUT]; the residual of virtual frame v is dropout_{site_e}(res[v % n_img]), computed here, so the
+    // T dropped copies are never written to HBM nor read back
+    int site_e;
 };
 
 __device__ __forceinline__ TailParams tail_group_params(const TailParams& q) {
@@ -1414,7 +1418,7 @@ __device__ __forceinline__ int tail_sw(int row) {
 
 // COUT_ = 0: the bottleneck's 4*CMID.  HAS_RES / RELU = false and in_stride = 2 turn conv_c alone into the projection
 // shortcut of a stage's first block (1x1 / 2, no residual, no ReLU, no dropout).
-template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32, int COUT_ = 0, bool HAS_RES = true, bool RELU = true>
+template <int CMID, int NRED, bool HAS3X3, int NS, int NW, bool WC2, int RP = 32, int COUT_ = 0, bool HAS_RES = true, bool RELU = true, bool RESE = false>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailParams p_launch, int patch_bytes) {
     const TailParams p = tail_group_params(p_launch);
     // Y is stored in whole 128-byte lines from an LDS image of the chunk: the one conv_a reads (NRED > 0), or - behind a staged-patch
@@ -1510,12 +1514,25 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     } while (0)
     if (tid < 64) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
     // the residual of chunk 0 comes from HBM: requested now, it lands under conv_b instead of in front of P2's first epilogue
-    const __amdgpu_buffer_rsrc_t srd_res =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((HAS_RES ? p.res : p.y) + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_res = RESE
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)((long long)p.drop.n_img * p.HW * COUT * 2), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)((HAS_RES ? p.res : p.y) + (long long)m0 * COUT), 0, rows_valid * COUT * 2, 0x00020000);
+    uint32_t eoff[TM2];          // RESE: byte offset of this lane's pixel rows in the cached tensor (frame v % n_img)
+    if constexpr (RESE) {
+#pragma unroll
+        for (int b = 0; b < TM2; ++b) {
+            const uint32_t m = (uint32_t)(m0 + wave * RP + b * 16 + frow);
+            const uint32_t vl = fastdiv(m, p.div_hw);
+            const uint32_t v = (uint32_t)p.drop.v0 + vl;
+            const uint32_t il = v - fastdiv(v, p.drop.div_img) * (uint32_t)p.drop.n_img;
+            eoff[b] = m < (uint32_t)p.M ? (il * (uint32_t)p.HW + (m - vl * (uint32_t)p.HW)) * (uint32_t)(COUT * 2) : 0x80000000u;
+        }
+    }
     u32x4_t rnext[TM2][2];
 #define FAV_T_LOAD_RES(J)                                                                                        \
     if (HAS_RES) _Pragma("unroll") for (int b = 0; b < TM2; ++b) {                                               \
-        const int off = ((wave * RP + b * 16 + frow) * COUT + (J) * 64 + fq * 16) * 2;                           \
+        const int off = RESE ? (int)(eoff[b] + (uint32_t)(((J) * 64 + fq * 16) * 2))                             \
+                             : ((wave * RP + b * 16 + frow) * COUT + (J) * 64 + fq * 16) * 2;                    \
         rnext[b][0] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off, 0, 0);                                 \
         rnext[b][1] = __builtin_amdgcn_raw_buffer_load_b128(srd_res, off + 16, 0, 0);                            \
     }
@@ -1892,10 +1909,17 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 const int row = wave * RP + b * 16 + frow;
                 const int n = j * 64 + fq * 16;
                 uint32_t draws[4] = {~0u, ~0u, ~0u, ~0u};
+                uint32_t edraws[4] = {~0u, ~0u, ~0u, ~0u};
                 if (p.drop.site >= 0) {
                     const uint32_t chunk = (uint32_t)(((long long)drop_pix[b] * COUT + n) >> 4);
                     const uint4 w4 = drop_draws16(p.drop, drop_v[b], chunk);
                     draws[0] = w4.x; draws[1] = w4.y; draws[2] = w4.z; draws[3] = w4.w;
+                    if constexpr (RESE) {         // the entry site's draws for the same 16 elements of the same virtual frame
+                        DropParams de = p.drop;
+                        de.site = p.site_e;
+                        const uint4 e4 = drop_draws16(de, drop_v[b], chunk);
+                        edraws[0] = e4.x; edraws[1] = e4.y; edraws[2] = e4.z; edraws[3] = e4.w;
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
@@ -1903,7 +1927,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc2[2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]);
                     if (HAS_RES) {
-                        const uint32_t rw[4] = {rcur[b][g][0], rcur[b][g][1], rcur[b][g][2], rcur[b][g][3]};
+                        uint32_t rw[4] = {rcur[b][g][0], rcur[b][g][1], rcur[b][g][2], rcur[b][g][3]};
+                        if constexpr (RESE) {     // cached pixel -> the bf16 the entry dropout would have stored for this sample
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float lo = FAV_DROP_APPLY(bf16_bits_to_f32(rw[k] & 0xFFFFu), edraws, 8 * g + 2 * k, p.drop);
+                                const float hi = FAV_DROP_APPLY(bf16_bits_to_f32(rw[k] >> 16), edraws, 8 * g + 2 * k + 1, p.drop);
+                                rw[k] = pack_bf16x2(lo, hi);
+                            }
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             v[2 * k] = __fadd_rn(v[2 * k], bf16_bits_to_f32(rw[k] & 0xFFFFu));
@@ -2147,7 +2179,7 @@ __global__ __launch_bounds__(256) void entry_dropout_kernel(const uint4* __restr
 // ---------------------------------------------------------------------------
 struct EntryReduceParams {
     const uint16_t* x;        // cached prefix output [n_img][HW][C]
-    uint16_t* y;              // [n_out][HW][C]
+    uint16_t* y;              // [n_out][HW][C]; null: the dropped copies are not stored (the next tail recomputes them, RESE)
     const uint16_t* wa; const float* bias_a;     // [NRED][C]
     uint16_t* t1;             // [n_out][HW][NRED]
     int HW, M, n_out;         // M = n_img * HW pixels of the cached tensor
@@ -2244,7 +2276,7 @@ __global__ __launch_bounds__(256, 3) void entry_reduce_kernel(const EntryReduceP
                         o[k] = pack_bf16x2(lo, hi);
                     }
                     const u32x4_t ov = {o[0], o[1], o[2], o[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, srd_y, (int)(orow[b] * (uint32_t)(C * 2)) + (j * 64 + fq * 16 + 8 * g) * 2, 0, 0);
+                    if (p.y) __builtin_amdgcn_raw_buffer_store_b128(ov, srd_y, (int)(orow[b] * (uint32_t)(C * 2)) + (j * 64 + fq * 16 + 8 * g) * 2, 0, 0);
                     *(u32x4_t*)(ych + row * 128 + (((2 * fq + g) ^ (row & 7)) << 4)) = ov;
                 }
             }
@@ -2375,59 +2407,82 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 
 // Multi-head attention, head width 64, up to 256 tokens: one block (8 waves) per (frame, head).
 //   qkv [n][T][3D] bf16 (Q | K | V, head h = columns 64h..64h+63 of each)  ->  out [n][T][D] bf16
-// K (row-major, swizzled) and V^T live in LDS; a wave takes 16 queries at a time:
+// K and V live in LDS, both row-major (whole 16-byte chunks, XOR-swizzled); the second product's A operand - V^T, eight
+// consecutive keys of one channel per lane - is read with gfx950's transposing ds_read_b64_tr_b16 (two per fragment), so
+// nothing is scattered while staging.  A wave takes 16 queries at a time:
 //   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), x 1/8, keys >= T masked,
 //   row max / sum by the lane (sequential over its keys) and two xor-shuffles, e = fav_expf(s - max),
 //   p = e * (1 / sum) rounded to bf16 through a per-wave LDS strip, O = V^T P^T on MFMA over keys ascending.
 // The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate.
 // The block has one wave per query tile when the P strips of that many waves fit in LDS (197 tokens: 13 waves, one
 // pass, every wave busy), else 8 waves that take the tiles round robin.
+typedef short attn_v4s __attribute__((ext_vector_type(4)));
+// XOR on the 16-byte chunk index of V's 128-byte rows: the 8 rows x 32 bytes a 32-lane half of a transposed read touches
+// (rows r .. r+3 and r+8 .. r+11 of one 16-channel column pair) fall on 64 different banks; even, so a pair stays a pair
+__device__ __forceinline__ int attn_vsw(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
                                                          int heads) {
     extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
     const int nkt = (T + 15) >> 4;             // key tiles of 16
     const int Tp2 = ((T + 31) >> 5) << 5;      // keys padded for the 32-deep second product
-    const int vstride = Tp2 * 2 + 16;          // bytes per V^T / P row (the +16 spreads rows over the banks)
+    const int vstride = Tp2 * 2 + 16;          // bytes per P row (the +16 spreads rows over the banks)
     unsigned char* const Ks = asm_;                                   // [nkt*16][128 B], chunk ^= row & 7
-    unsigned char* const Vt = Ks + nkt * 16 * 128;                    // [64][vstride]
-    unsigned char* const Ps = Vt + 64 * vstride;                      // [waves][16][vstride]
+    unsigned char* const Vs = Ks + nkt * 16 * 128;                    // [Tp2][128 B], chunk ^= attn_vsw(row)
+    unsigned char* const Ps = Vs + Tp2 * 128;                         // [waves][16][vstride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthr = blockDim.x, nwaves = nthr >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int h = blockIdx.x % heads;
     const long long f = blockIdx.x / heads;
     const uint16_t* base = qkv + f * (long long)T * 3 * D;
-    // ---- stage K and V^T (zero beyond T) ----
-    for (int i = tid; i < nkt * 16 * 8; i += nthr) {
-        const int row = i >> 3, ch = i & 7;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < T) v = *(const uint4*)(base + (long long)row * 3 * D + D + h * 64 + ch * 8);
-        *(uint4*)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
-    }
-    for (int i = tid; i < Tp2 * 8; i += nthr) {
-        const int key = i >> 3, ch = i & 7;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (key < T) v = *(const uint4*)(base + (long long)key * 3 * D + 2 * D + h * 64 + ch * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int nqt = (T + 15) >> 4;
+    // the Q fragments of this wave's first query tile: requested before anything else
+    uint4 fq0[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    if (wave < nqt && wave * 16 + frow < T) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *(uint16_t*)(Vt + (ch * 8 + 2 * j) * vstride + key * 2) = (uint16_t)(w[j] & 0xFFFFu);
-            *(uint16_t*)(Vt + (ch * 8 + 2 * j + 1) * vstride + key * 2) = (uint16_t)(w[j] >> 16);
+        for (int kk = 0; kk < 2; ++kk) fq0[kk] = *(const uint4*)(base + (long long)(wave * 16 + frow) * 3 * D + h * 64 + kk * 32 + fq * 8);
+    }
+    // ---- stage K and V (zero beyond T): every global load first, then the LDS writes (at most 4 rounds: 256 keys, >= 512 threads)
+    {
+        uint4 kv[4], vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = tid + r * nthr, row = i >> 3, ch = i & 7;
+            kv[r] = make_uint4(0u, 0u, 0u, 0u);
+            vv[r] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < T) {
+                kv[r] = *(const uint4*)(base + (long long)row * 3 * D + D + h * 64 + ch * 8);
+                vv[r] = *(const uint4*)(base + (long long)row * 3 * D + 2 * D + h * 64 + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = tid + r * nthr, row = i >> 3, ch = i & 7;
+            if (row < nkt * 16) *(uint4*)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = kv[r];
+            if (row < Tp2) *(uint4*)(Vs + row * 128 + ((ch ^ attn_vsw(row)) << 4)) = vv[r];
         }
     }
     unsigned char* const Pw = Ps + wave * 16 * vstride;
     for (int i = lane; i < 16 * (vstride / 16); i += 64) *(uint4*)(Pw + i * 16) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
-    const int nqt = (T + 15) >> 4;
+    // transposed reads of V: lane 4q + p of a 16-lane group addresses row (key) r0 + q, channels 4p .. 4p + 3 of the block
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int vsw_l = attn_vsw(8 * fq + tq);       // = attn_vsw of every row this lane addresses (rows 32*ks + 8*fq + tq (+ 4))
+    const unsigned char* const vbase = Vs + (8 * fq + tq) * 128 + ((tp >> 1) << 4) + 8 * (tp & 1);
+
     for (int qt = wave; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + frow;          // this lane's query (as MFMA column)
         uint4 fqv[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            fqv[kk] = make_uint4(0u, 0u, 0u, 0u);
-            if (q < T) fqv[kk] = *(const uint4*)(base + (long long)q * 3 * D + h * 64 + kk * 32 + fq * 8);
+            fqv[kk] = fq0[kk];
+            if (qt != wave) {
+                fqv[kk] = make_uint4(0u, 0u, 0u, 0u);
+                if (q < T) fqv[kk] = *(const uint4*)(base + (long long)q * 3 * D + h * 64 + kk * 32 + fq * 8);
+            }
         }
         f32x4_t sc[16];
 #pragma unroll
@@ -2498,7 +2553,12 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
             const uint4 fp = *(const uint4*)(Pw + frow * vstride + (ks * 32 + fq * 8) * 2);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 fv = *(const uint4*)(Vt + (dt * 16 + frow) * vstride + (ks * 32 + fq * 8) * 2);
+                // V^T fragment: channel dt*16 + frow, keys 32*ks + 8*fq .. + 7 = two transposed 4-key x 16-channel blocks
+                const unsigned char* va = vbase + ks * 4096 + (((2 * dt) ^ vsw_l) << 4);
+                const attn_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_v4s*)(va));
+                const attn_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_v4s*)(va + 512));
+                const uint2 t0u = __builtin_bit_cast(uint2, t0), t1u = __builtin_bit_cast(uint2, t1);
+                const uint4 fv = make_uint4(t0u.x, t0u.y, t1u.x, t1u.y);
                 if (MODE == 0) {
                     union { uint4 u; bf16x8_t v; } ua, ub;
                     ua.u = fv; ub.u = fp;

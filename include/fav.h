@@ -200,6 +200,10 @@ typedef struct fav_tail_desc {
     void* t1n;                              /* [n][H][W][Nred] bf16 */
     int32_t n_frames, H, W, Cmid, Nred;
     fav_dropout_desc drop;
+    /* res_entry != 0 (Cmid = Nred = 64 with the 3x3, drop.site >= 0): `res` is the CACHED prefix output
+     * [drop.n_img][H][W][4*Cmid] and the residual of virtual frame v is dropout_{entry_site}(res[v % n_img]) - what
+     * fav_op_entry_dropout / fav_op_entry_reduce would have stored for it (same bits), computed in the epilogue instead */
+    int32_t res_entry, entry_site;
 } fav_tail_desc;
 fav_status fav_op_bottleneck_tail(const fav_tail_desc* d, void* hip_stream);
 /* frames (u8 or fp32 NHWC3) -> normalised bf16 im2col matrix [n*Ho*Wo][kpad] */
@@ -219,7 +223,8 @@ fav_status fav_op_entry_dropout(const void* x, void* out, int64_t elems_per_fram
                                 const fav_dropout_desc* drop, void* hip_stream);
 /* entry dropout and the 1x1 reduce behind it in one launch (C = 256, Nred = 64):
  * y[v - v0] = dropout(x[v % n_img]) as above, t1[v - v0] = bf16(relu(conv1x1(y[v - v0], wa) + bias_a)); x [n_img][HW][C],
- * wa [Nred][C] bf16.  The executor's fusion of the MC-Dropout suffix's first two launches (no reference counterpart). */
+ * wa [Nred][C] bf16.  The executor's fusion of the MC-Dropout suffix's first two launches (no reference counterpart).
+ * y may be NULL: the dropped copies are then not stored (a tail with res_entry recomputes them). */
 fav_status fav_op_entry_reduce(const void* x, void* y, const void* wa, const float* bias_a, void* t1, int32_t C, int32_t Nred,
                                int32_t HW, int32_t n_out, const fav_dropout_desc* drop, void* hip_stream);
 /* logits fp32 [T][n][ld] -> labels, conf (and fail/score if non-NULL) */

@@ -148,3 +148,61 @@ def test_wide_projection_shortcut_on_the_row_owning_kernel(lib, stride, H, W, n)
         xs, ws = x[sl].float().cpu().numpy(), w.float().cpu().numpy()
         ref = O.epilogue(O.conv_acc_exact(xs, ws, 1, 1, stride, 0, mode="mfma"), b.cpu().numpy(), relu=False)
         assert np.array_equal(y[sl].float().cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("H,W,n_img,v0,n_out", [(56, 56, 3, 0, 9), (20, 12, 4, 2, 9), (7, 9, 5, 13, 37), (60, 80, 2, 1, 3)])
+def test_tail_entry_residual_recomputes_the_dropped_copies(lib, H, W, n_img, v0, n_out):
+    """res_entry: the tail behind the entry dropout of an MC-Dropout suffix takes its residual from the CACHED prefix
+    output x0 [n_img] - virtual frame v reads frame v % n_img and applies the entry site's mask in the epilogue - and gives
+    the bits of the same tail fed with the stored dropped copies (fav_op_entry_reduce with y), for chunks of virtual
+    frames that start inside a sample, wrap around the cached frames and end in a ragged tile; and entry_reduce with
+    y = NULL still writes the same t1."""
+    rng = np.random.default_rng(H * W + n_img * 7 + v0)
+    cmid, cout, nred = 64, 256, 64
+    thr, seed, first, site_e, site_o = 26, 0x1234567ABC, 40, 2, 3
+    x0 = O.bf16_round(np.maximum(rng.standard_normal((n_img, H, W, cout)), 0).astype(np.float32))
+    wa0 = O.bf16_round((rng.standard_normal((nred, 1, 1, cout)) * np.sqrt(2.0 / cout)).astype(np.float32))
+    ba0 = (rng.standard_normal(nred) * 0.2).astype(np.float32)
+    wb = O.bf16_round((rng.standard_normal((cmid, 3, 3, cmid)) * np.sqrt(2.0 / (9 * cmid))).astype(np.float32))
+    bb = (rng.standard_normal(cmid) * 0.2).astype(np.float32)
+    wc = O.bf16_round((rng.standard_normal((cout, 1, 1, cmid)) * np.sqrt(1.0 / cmid)).astype(np.float32))
+    bc = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    wa = O.bf16_round((rng.standard_normal((nred, 1, 1, cout)) * np.sqrt(2.0 / cout)).astype(np.float32))
+    ba = (rng.standard_normal(nred) * 0.2).astype(np.float32)
+    scale = float(O.dropout_scale(thr))
+    de = drop_desc(site=site_e, thr=thr, scale=scale, seed=seed, v0=v0, n_img=n_img, first=first)
+    do = drop_desc(site=site_o, thr=thr, scale=scale, seed=seed, v0=v0, n_img=n_img, first=first)
+    x0d, wa0d, ba0d = dev_bf16(x0), dev_bf16(wa0.reshape(nred, cout)), torch.from_numpy(ba0).cuda()
+    # the stored form: entry dropout + reduce -> y0 (dropped copies), t1
+    y0 = torch.zeros((n_out, H, W, cout), dtype=torch.bfloat16, device="cuda")
+    t1 = torch.zeros((n_out, H, W, nred), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.fav_op_entry_reduce(x0d.data_ptr(), y0.data_ptr(), wa0d.data_ptr(), ba0d.data_ptr(), t1.data_ptr(), cout, nred,
+                                       H * W, n_out, C.byref(de), None))
+    t1b = torch.zeros_like(t1)
+    _lib.check(lib.fav_op_entry_reduce(x0d.data_ptr(), None, wa0d.data_ptr(), ba0d.data_ptr(), t1b.data_ptr(), cout, nred,
+                                       H * W, n_out, C.byref(de), None))
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t1b)
+    y_ref, t1n_ref = run_tail(lib, host_f32(t1), wb, bb, wc, bc, host_f32(y0), wa, ba, drop=do)
+    # the recomputed form
+    keep = [t1, dev_bf16(wb), torch.from_numpy(bb).cuda(), dev_bf16(wc), torch.from_numpy(bc).cuda(), dev_bf16(wa), torch.from_numpy(ba).cuda()]
+    y = torch.zeros((n_out, H, W, cout), dtype=torch.bfloat16, device="cuda")
+    t1n = torch.zeros((n_out, H, W, nred), dtype=torch.bfloat16, device="cuda")
+    d = _lib.FavTailDesc(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+                         x0d.data_ptr(), y.data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(), t1n.data_ptr(),
+                         n_out, H, W, cmid, nred, do, 1, site_e)
+    _lib.check(lib.fav_op_bottleneck_tail(C.byref(d), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(host_f32(y), y_ref), f"Y: {np.mean(host_f32(y) != y_ref):.5f} of elements differ"
+    assert np.array_equal(host_f32(t1n), t1n_ref)
+    # and the dropped copies really are dropout_{site_e}(x0[v % n_img]) as the oracle draws it
+    v = v0 + np.arange(n_out)
+    keepm = np.stack([O.dropout_keep(seed, int(tt), site_e, np.array([ii]), H * W * cout, thr)[0]
+                      for tt, ii in zip(v // n_img, v % n_img + first)]).reshape(n_out, H, W, cout)
+    exp = O.bf16_round(np.where(keepm, x0[v % n_img] * np.float32(scale), 0).astype(np.float32))
+    assert np.array_equal(host_f32(y0), exp)
+    # unsupported uses are refused
+    bad = _lib.FavTailDesc(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+                           x0d.data_ptr(), y.data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(), t1n.data_ptr(),
+                           n_out, H, W, cmid, nred, drop_desc(), 1, site_e)
+    assert lib.fav_op_bottleneck_tail(C.byref(bad), None) != 0
