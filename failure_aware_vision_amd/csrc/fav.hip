@@ -583,6 +583,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     p.g_t1 = G.x; p.g_res = G.res; p.g_y = G.y; p.g_t1n = G.y2;
     p.g_wb = G.wb; p.g_bb = G.bb; p.g_wc = G.w; p.g_bc = G.b; p.g_wa = G.wa; p.g_ba = G.ba;
     p.site_e = d.entry_site;
+    p.rs_T = 0; p.rs_tps = 0;
     if (d.res_entry) {
         if (!(d.Cmid == 64 && nred == 64 && has3x3) || p.drop.site < 0 || d.entry_site < 0 || !d.res)
             return "bottleneck tail: res_entry needs Cmid = Nred = 64 with the 3x3 and both dropout sites";
@@ -639,6 +640,13 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
 #define FAV_TAIL_W(CMID_, NRED_, H3_, NS_, NW_) do { if (g.wc2) FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, true); else FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, false); } while (0)
 #define FAV_TAIL_N(CMID_, NRED_, H3_, NS_) FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 4)
     if (d.res_entry) {
+        // whole samples, tiles that do not straddle them: the T tiles over one pixel tile of the cached tensor run back to back
+        static const bool sample_minor = [] { const char* e = getenv("FAV_ENTRY_RES_ORDER"); return !e || atoi(e) != 0; }();
+        const long long sample_rows = (long long)p.drop.n_img * p.HW;
+        if (sample_minor && p.drop.v0 % p.drop.n_img == 0 && d.n_frames % p.drop.n_img == 0 && sample_rows % bm == 0) {
+            p.rs_T = d.n_frames / p.drop.n_img;
+            p.rs_tps = (int)(sample_rows / bm);
+        }
         static DeviceFlags attr_set;
         auto k0 = bottleneck_tail_kernel<64, 64, true, 3, 4, false, 32, 0, true, true, true>;
         auto k1 = bottleneck_tail_kernel<64, 64, true, 3, 4, true, 32, 0, true, true, true>;

@@ -1379,6 +1379,7 @@ struct TailParams {
     // [drop.n_img][HW][COUT]; the residual of virtual frame v is dropout_{site_e}(res[v % n_img]), computed here, so the
     // T dropped copies are never written to HBM nor read back
     int site_e;
+    int rs_T, rs_tps;         // RESE tile order: samples in the launch, tiles per sample (rs_T <= 1: row order)
 };
 
 __device__ __forceinline__ TailParams tail_group_params(const TailParams& q) {
@@ -1480,6 +1481,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     {
         const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    if constexpr (RESE) {
+        // sample-minor order: an XCD's consecutive tiles are the rs_T samples of ONE pixel tile of the cached tensor, so the
+        // residual of that tile comes from HBM once and from the XCD's L2 for the other samples
+        if (p.rs_T > 1) {
+            const int pt = tile / p.rs_T, t = tile - pt * p.rs_T;
+            tile = t * p.rs_tps + pt;
+        }
     }
     const int m0 = tile * BM;
     const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;

@@ -150,7 +150,8 @@ def test_wide_projection_shortcut_on_the_row_owning_kernel(lib, stride, H, W, n)
         assert np.array_equal(y[sl].float().cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("H,W,n_img,v0,n_out", [(56, 56, 3, 0, 9), (20, 12, 4, 2, 9), (7, 9, 5, 13, 37), (60, 80, 2, 1, 3)])
+@pytest.mark.parametrize("H,W,n_img,v0,n_out", [(56, 56, 3, 0, 9), (20, 12, 4, 2, 9), (7, 9, 5, 13, 37), (60, 80, 2, 1, 3),
+                                                (16, 16, 2, 4, 6), (8, 16, 3, 0, 6), (56, 56, 4, 0, 12)])   # whole samples of whole tiles: sample-minor tile order
 def test_tail_entry_residual_recomputes_the_dropped_copies(lib, H, W, n_img, v0, n_out):
     """res_entry: the tail behind the entry dropout of an MC-Dropout suffix takes its residual from the CACHED prefix
     output x0 [n_img] - virtual frame v reads frame v % n_img and applies the entry site's mask in the epilogue - and gives
