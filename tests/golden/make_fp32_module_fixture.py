@@ -3,10 +3,10 @@ path"; the reference lists torch at requirements.txt:1-2 and never imports it, s
 
 The synthetic checkpoint IS an fp32 state_dict (weights.make_synthetic_state_dict; the FAVW blob is its fold), so
 tests/torch_models.ResNet("resnet50") loads it as it is: BatchNorm un-folded, fp32 weights, fp32 activations, no bf16
-anywhere, eval().  Labels / confidences / top-2 gaps of the first 1,000 corrupted frames are stored; the GPU test
+anywhere, eval().  Labels / confidences / top-2 gaps of the 10,000 corrupted frames are stored; the GPU test
 prints the agreement of the production mode with them and asserts a bound derived from it.
 
-  python tests/golden/make_fp32_module_fixture.py      # ~2 min on 8 cores -> tests/golden/r50_fp32_module_1k.npz
+  python tests/golden/make_fp32_module_fixture.py [n]  # ~10 min on 8 cores -> tests/golden/r50_fp32_module_10k.npz
 """
 import os, sys, time
 import numpy as np
@@ -22,7 +22,7 @@ sd, meta = weights.make_synthetic_state_dict("resnet50", seed=1)
 blob, info = weights.from_state_dict("resnet50", sd, bn_eps=meta["bn_eps"])
 net, meta = load_synthetic("resnet50", seed=1)
 mean = np.asarray(meta["mean"], np.float32); std = np.asarray(meta["std"], np.float32)
-n, bs = 1000, 50
+n, bs = (int(sys.argv[1]) if len(sys.argv) > 1 else 10000), 50
 labels = np.zeros(n, np.int16); conf = np.zeros(n, np.float32); gap = np.zeros(n, np.float32); top2 = np.zeros(n, np.int16)
 t0 = time.time()
 with torch.no_grad():
@@ -36,8 +36,8 @@ with torch.no_grad():
         conf[s:s + bs] = pb[np.arange(bs), srt[:, -1]]
         gap[s:s + bs] = pb[np.arange(bs), srt[:, -1]] - pb[np.arange(bs), srt[:, -2]]
         print(s + bs, round(time.time() - t0, 1), flush=True)
-np.savez_compressed(os.path.join(HERE, "r50_fp32_module_1k.npz"), labels=labels, conf=conf, gap=gap, second=top2,
+np.savez_compressed(os.path.join(HERE, "r50_fp32_module_%dk.npz" % (n // 1000)), labels=labels, conf=conf, gap=gap, second=top2,
                     blob_sha256=info["sha256"],
                     meta="resnet50 seed1 as an fp32 torch nn.Module (BatchNorm un-folded, eval, torch %s CPU); frames seed 21 ids "
-                         "0..999 + gaussian noise sev3 seed 3; single pass; gap = top-1 minus top-2 probability" % torch.__version__)
+                         "0..%d + gaussian noise sev3 seed 3; single pass; gap = top-1 minus top-2 probability" % (torch.__version__, n - 1))
 print("done")

@@ -151,14 +151,14 @@ def test_ten_thousand_corrupted_frames(r50_blob):
       confidences within 3e-6;
     * independent evidence, printed and bounded: production mode against oracle/torch_cpu.py on all 10,000 frames
       (torch.nn.functional fp32 convolutions in the library's own order, bf16 layer boundaries: r50_torchcpu_10k.npz) and
-      against the PURE fp32 nn.Module on the first 1,000 (BatchNorm un-folded, no bf16 anywhere: r50_fp32_module_1k.npz,
+      against the PURE fp32 nn.Module, also on all 10,000 (BatchNorm un-folded, no bf16 anywhere: r50_fp32_module_10k.npz,
       the "stated tolerance" of north_star; reference anchor requirements.txt:1-2) - neither knows the MFMA adder;
     * production vs validation mode (same operands, different adder), printed and bounded."""
     blob, info = r50_blob
     gm = load("r50_mfma_10k_noise3.npz", info)
     ge = load("r50_exact_10k_noise3.npz", info)
     gt = load("r50_torchcpu_10k.npz", info)
-    gf = load("r50_fp32_module_1k.npz", info)
+    gf = load("r50_fp32_module_10k.npz", info)
     n, bs = len(gm["labels"]), 250
     assert n == 10000 and len(ge["labels"]) == n and len(gt["labels"]) == n
     exact = Backend("resnet50", blob, max_batch=bs, math_mode="f32_exact")
@@ -207,15 +207,16 @@ def test_ten_thousand_corrupted_frames(r50_blob):
     assert np.all(tgap[bad] < 0.06), tgap[bad].max()
     assert second >= 0.9
     assert np.abs(cf - gt["conf"]).max() < 0.04
-    # production vs the pure fp32 nn.Module, first 1,000 frames: the stated tolerance
+    # production vs the pure fp32 nn.Module, all 10,000 frames: the stated tolerance
     m = len(gf["labels"])
     ref, fgap = gf["labels"].astype(np.int32), gf["gap"]
     bad = lf[:m] != ref
     second = (lf[:m][bad] == gf["second"][bad]).mean() if bad.any() else 1.0
     dconf = np.abs(cf[:m] - gf["conf"])
-    note(f"first {m} frames, production (bf16 MFMA) vs pure fp32 nn.Module: {m - bad.sum()} / {m} labels equal; largest fp32 top-2 gap "
+    note(f"{m} frames, production (bf16 MFMA) vs pure fp32 nn.Module: {m - bad.sum()} / {m} labels equal; largest fp32 top-2 gap "
          f"among the disagreements {fgap[bad].max() if bad.any() else 0:.4f}; GPU label is the module's second choice in {second:.2f} "
          f"of them; |dconf| max {dconf.max():.4f}, mean {dconf.mean():.4f}")
-    # measured: 990 / 1,000 equal, largest gap 0.033, always the module's second choice, |dconf| max 0.061 / mean 0.0068
-    assert bad.mean() <= 0.02 and np.all(fgap[bad] < 0.05) and second >= 0.8
-    assert dconf.max() < 0.09 and dconf.mean() < 0.012
+    # measured: 9,890 / 10,000 equal (990 of the first 1,000), largest gap 0.083 (77 of the 110 below 0.02), the module's second
+    # choice in 0.99 of them, |dconf| max 0.085 / mean 0.0064
+    assert m == n and bad.mean() <= 0.016 and np.all(fgap[bad] < 0.12) and second >= 0.9
+    assert dconf.max() < 0.12 and dconf.mean() < 0.01
