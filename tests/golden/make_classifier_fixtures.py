@@ -4,7 +4,7 @@ the fixtures hold only expected outputs.
 
   python tests/golden/make_classifier_fixtures.py mc       # 64 frames, T=30 all_blocks            (~3 min on 8 AVX-512 cores)
   python tests/golden/make_classifier_fixtures.py 10k      # 10,000 frames, single pass            (~10 min)
-  python tests/golden/make_classifier_fixtures.py mfma_mc  # 16 frames, T=30 all_blocks, production bf16-MFMA model (~3 min)
+  python tests/golden/make_classifier_fixtures.py mfma_mc  # 64 frames, T=30 all_blocks, production bf16-MFMA model (~15 min)
   python tests/golden/make_classifier_fixtures.py mfma_10k # 10,000 frames, single pass, production bf16-MFMA model (~1 h; resumes)
   python tests/golden/make_classifier_fixtures.py vit     # ViT-B/16, 16 corrupted frames, production bf16-MFMA model
   python tests/golden/make_classifier_fixtures.py ens5    # BASELINE configs[3]: 5 ResNet-50 members (seeds 1..5), 16 frames, production model
@@ -93,7 +93,7 @@ elif what == "mc":
                         conf=np.concatenate(conf), gap=np.concatenate(gaps), blob_sha256=info["sha256"],
                         meta="resnet50 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; exact")
 elif what == "mfma_mc":
-    n, T = 16, 30
+    n, T = 64, 30
     cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact="mfma")
     labels, conf, gaps, logits = [], [], [], []
     for s in range(0, n, 4):
@@ -101,10 +101,10 @@ elif what == "mfma_mc":
         l, c, lg, pb = O.classify(model, frames(s, 4), cfg, img_ids=np.arange(s, s + 4), return_logits=True)
         labels.append(l); conf.append(c); gaps.append(gap_of(pb)); logits.append(frame_crc(lg))
         print("mfma_mc", s, time.time() - t0, flush=True)
-    np.savez_compressed(os.path.join(HERE, "r50_mfma_mc30_16.npz"), labels=np.concatenate(labels).astype(np.int16),
+    np.savez_compressed(os.path.join(HERE, "r50_mfma_mc30_64.npz"), labels=np.concatenate(labels).astype(np.int16),
                         conf=np.concatenate(conf), gap=np.concatenate(gaps), logit_crc32=np.concatenate(logits),
                         blob_sha256=info["sha256"],
-                        meta="resnet50 seed1; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; "
+                        meta="resnet50 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; "
                              "production mode (v_mfma_f32_16x16x32_bf16 model)")
 elif what == "mfma_10k":
     # north_star's "label-exact agreement on 10k corrupted test frames" in the arithmetic that ships: the same 10,000

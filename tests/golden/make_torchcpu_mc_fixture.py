@@ -1,9 +1,10 @@
 """Independent labels / confidences for the HEADLINE configuration: oracle/torch_cpu.py (torch.nn.functional fp32 CPU
-convolutions, bf16 rounding at every layer boundary, the library's own summation order) on 64 corrupted frames with
+convolutions, bf16 rounding at every layer boundary, the library's own summation order) on 256 corrupted frames - the
+headline batch - with
 MC-Dropout T = 30, `all_blocks`, p = 0.1, seed 4 - the same Philox masks, prefix caching and mean-of-softmax head as the
 GPU path, none of its arithmetic.  (make_torchcpu_fixture.py is the single-pass counterpart.)
 
-  python tests/golden/make_torchcpu_mc_fixture.py     # ~2 min on 8 cores -> tests/golden/r50_torchcpu_mc30_64.npz
+  python tests/golden/make_torchcpu_mc_fixture.py     # ~11 min on 8 cores -> tests/golden/r50_torchcpu_mc30_256.npz
 """
 import os, sys, time
 import numpy as np
@@ -18,7 +19,7 @@ FRAME_SEED, NOISE_SEED, SEVERITY = 21, 3, 3
 blob, info = weights.make_synthetic("resnet50", seed=1)
 model = O.parse_blob(blob)
 net = TC.TorchNet(model)
-n, bs = 64, 4
+n, bs = 256, 4
 cfg = O.ClassifyConfig(n_samples=30, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4)
 labels = np.zeros(n, np.int16); conf = np.zeros(n, np.float32); gap = np.zeros(n, np.float32); top2 = np.zeros(n, np.int16)
 t0 = time.time()
@@ -31,9 +32,9 @@ for s in range(0, n, bs):
     top2[s:s + bs] = srt[:, -2]
     gap[s:s + bs] = pb[np.arange(bs), srt[:, -1]] - pb[np.arange(bs), srt[:, -2]]
     print(s + bs, round(time.time() - t0, 1), flush=True)
-np.savez_compressed(os.path.join(HERE, "r50_torchcpu_mc30_64.npz"), labels=labels, conf=conf, gap=gap, second=top2,
+np.savez_compressed(os.path.join(HERE, "r50_torchcpu_mc30_256.npz"), labels=labels, conf=conf, gap=gap, second=top2,
                     blob_sha256=info["sha256"],
-                    meta="resnet50 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; MC-Dropout T=30 all_blocks p=0.1 seed 4; "
+                    meta="resnet50 seed1; frames seed 21 ids 0..255 + gaussian noise sev3 seed 3; MC-Dropout T=30 all_blocks p=0.1 seed 4; "
                          "oracle/torch_cpu.py (torch %s fp32 CPU convolutions, bf16 layer boundaries); gap = top-1 minus top-2 mean "
                          "probability" % __import__("torch").__version__)
 print("done")
