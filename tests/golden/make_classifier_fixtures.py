@@ -6,8 +6,8 @@ the fixtures hold only expected outputs.
   python tests/golden/make_classifier_fixtures.py 10k      # 10,000 frames, single pass            (~10 min)
   python tests/golden/make_classifier_fixtures.py mfma_mc  # 64 frames, T=30 all_blocks, production bf16-MFMA model (~15 min)
   python tests/golden/make_classifier_fixtures.py mfma_10k # 10,000 frames, single pass, production bf16-MFMA model (~1 h; resumes)
-  python tests/golden/make_classifier_fixtures.py vit     # ViT-B/16, 16 corrupted frames, production bf16-MFMA model
-  python tests/golden/make_classifier_fixtures.py ens5    # BASELINE configs[3]: 5 ResNet-50 members (seeds 1..5), 16 frames, production model
+  python tests/golden/make_classifier_fixtures.py vit     # ViT-B/16, 64 corrupted frames, production bf16-MFMA model
+  python tests/golden/make_classifier_fixtures.py ens5    # BASELINE configs[3]: 5 ResNet-50 members (seeds 1..5), 256 frames, production model (~8 min)
 """
 import os, sys, time, zlib
 import numpy as np
@@ -43,7 +43,7 @@ def gap_of(pbar):
 
 
 if what == "vit":
-    n = 16
+    n = 64                                  # the config's per-GPU share
     cfg = O.ClassifyConfig(exact="mfma", temperature=1.5, conf_kind=O.CONF_ENTROPY)
     labels, conf, gaps, crcs = [], [], [], []
     for s in range(0, n, 4):
@@ -51,15 +51,15 @@ if what == "vit":
         l, c, lg, pb = O.classify(model, frames(s, 4), cfg, return_logits=True)
         labels.append(l); conf.append(c); gaps.append(gap_of(pb)); crcs.append(frame_crc(lg))
         print("vit", s, time.time() - t0, flush=True)
-    np.savez_compressed(os.path.join(HERE, "vit_b16_mfma_16.npz"), labels=np.concatenate(labels).astype(np.int16),
+    np.savez_compressed(os.path.join(HERE, "vit_b16_mfma_64.npz"), labels=np.concatenate(labels).astype(np.int16),
                         conf=np.concatenate(conf), gap=np.concatenate(gaps), logit_crc32=np.concatenate(crcs),
                         blob_sha256=info["sha256"],
-                        meta="vit_b16 seed1; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; single pass, entropy "
+                        meta="vit_b16 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; single pass, entropy "
                              "confidence at temperature 1.5; production mode (v_mfma_f32_16x16x32_bf16 model)")
 elif what == "ens5":
     # BASELINE configs[3]: five independently seeded ResNet-50 members, 224x224, severity-3 frames, single pass per
     # member, head = mean over members of softmax.  Per member and frame: CRC-32 of the 1000 fp32 logits.
-    n, seeds = 16, (1, 2, 3, 4, 5)
+    n, seeds = 256, (1, 2, 3, 4, 5)        # the config's global batch
     cfg = O.ClassifyConfig(exact="mfma")
     x = frames(0, n)
     lgs, shas = [], []
@@ -74,10 +74,10 @@ elif what == "ens5":
     lg = np.stack(lgs)                                          # [5, n, 1000]: the head sees members as samples
     l, c, pb = O.confidence_head(lg)
     crc = np.array([[zlib.crc32(np.ascontiguousarray(lg[m, i]).tobytes()) for i in range(n)] for m in range(len(seeds))], np.uint32)
-    np.savez_compressed(os.path.join(HERE, "r50_ens5_mfma_16.npz"), labels=l.astype(np.int16), conf=c, gap=gap_of(pb),
+    np.savez_compressed(os.path.join(HERE, "r50_ens5_mfma_256.npz"), labels=l.astype(np.int16), conf=c, gap=gap_of(pb),
                         member_logit_crc32=crc, member_blob_sha256=np.array(shas), member_seeds=np.array(seeds),
                         member_labels=lg.argmax(axis=2).astype(np.int16), blob_sha256=shas[0],
-                        meta="5 x resnet50 seeds 1..5; frames seed 21 ids 0..15 + gaussian noise sev3 seed 3; single pass per member, "
+                        meta="5 x resnet50 seeds 1..5; frames seed 21 ids 0..255 + gaussian noise sev3 seed 3; single pass per member, "
                              "mean of member softmax; production mode (v_mfma_f32_16x16x32_bf16 model); member_logit_crc32[m][i] = "
                              "zlib.crc32 of member m's 1000 fp32 logits of frame i")
 elif what == "mc":

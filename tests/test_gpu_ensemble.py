@@ -4,7 +4,7 @@ counterpart; the slot it feeds is platform/backend/main.py:160).
 
 * production mode (bf16 MFMA) and validation mode (fp32 chain): the logits [5][n][1000] of every member are
   bit-equal to the CPU oracle's, run live here on the same seeded frames;
-* production mode against the committed fixture tests/golden/r50_ens5_mfma_16.npz (per member and frame CRC-32
+* production mode against the committed fixture tests/golden/r50_ens5_mfma_256.npz - the config's global batch of 256 frames - (per member and frame CRC-32
   of the 1000 logits; generator: tests/golden/make_classifier_fixtures.py ens5);
 * at the per-GPU share of the 8-GPU configuration (32 frames per call): member independence (member m's logits
   equal a single-model handle loaded with checkpoint m), shard invariance and determinism.
@@ -52,9 +52,9 @@ def test_ens5_resnet50_224_logits_bitwise_vs_oracle(r50_members, mode, exact):
 
 
 def test_ens5_production_fixture(r50_members):
-    path = os.path.join(GOLD, "r50_ens5_mfma_16.npz")
+    path = os.path.join(GOLD, "r50_ens5_mfma_256.npz")
     if not os.path.exists(path):
-        pytest.skip("r50_ens5_mfma_16.npz not generated yet")
+        pytest.skip("r50_ens5_mfma_256.npz not generated yet")
     d = np.load(path)
     assert [i["sha256"] for _, i in r50_members] == [str(s) for s in d["member_blob_sha256"]], "different checkpoints"
     n = len(d["labels"])

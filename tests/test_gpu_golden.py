@@ -98,11 +98,11 @@ def test_headline_config_vs_independent_torch_cpu(r50_blob):
 
 
 def test_vit_b16_production_mode_fixture():
-    """BASELINE configs[4]: ViT-B/16 on 16 corrupted 224x224 frames, entropy confidence at temperature 1.5,
+    """BASELINE configs[4]: ViT-B/16 on 64 corrupted 224x224 frames (the per-GPU share of its global batch), entropy confidence at temperature 1.5,
     PRODUCTION bf16 mode: every logit bit-identical to the fixture (per-frame CRC-32), labels exactly equal."""
     from failure_aware_vision_amd import weights
     blob, info = weights.make_synthetic_vit("vit_b16", seed=1)
-    d = load("vit_b16_mfma_16.npz", info)
+    d = load("vit_b16_mfma_64.npz", info)
     n = len(d["labels"])
     be = Backend("vit_b16", blob, max_batch=n, temperature=1.5, conf_kind="entropy")
     labels, conf = be.classify(frames(0, n))
