@@ -13,8 +13,9 @@ ap.add_argument("--chunk-a", type=int, default=0)
 ap.add_argument("--chunk-b", type=int, default=0)
 ap.add_argument("--regroup-block", type=int, default=-1)
 ap.add_argument("--out", default="")
+ap.add_argument("--members", type=int, default=1, help="deep ensemble of this many independently seeded members (policy none)")
 a = ap.parse_args()
-blob, _ = weights.make_synthetic("resnet50", seed=1)
+blob = weights.make_synthetic("resnet50", seed=1)[0] if a.members == 1 else [weights.make_synthetic("resnet50", seed=1 + m)[0] for m in range(a.members)]
 T = a.samples if a.policy != "none" else 1
 be = Backend("resnet50", blob, max_batch=a.batch, n_samples=T, dropout_policy=a.policy,
              dropout_p=0.1 if a.policy != "none" else 0.0, seed=4, chunk_a=a.chunk_a, chunk_b=a.chunk_b,
