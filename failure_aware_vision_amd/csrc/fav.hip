@@ -607,6 +607,9 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
         std::vector<unsigned long long> t((size_t)nblocks * 16);
         (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(p.dbg);
+        if (const char* dump = getenv("FAV_CONV_DBG_DUMP")) {     // raw stamps, [block][16] u64, appended: tools/phase_overlap.py
+            if (FILE* f = fopen(dump, "ab")) { const long long hdr[2] = {nblocks, cmid * 1000 + nred}; fwrite(hdr, 8, 2, f); fwrite(t.data(), 8, t.size(), f); fclose(f); }
+        }
         unsigned long long lo = ~0ull, hi = 0;
         double ph[5] = {0, 0, 0, 0, 0};
         double cy[5] = {0, 0, 0, 0, 0};   // chunk 1 of wave 0, shader clocks: step A | epilogue | step C | DMA wait | barrier

@@ -5,6 +5,7 @@ the fixtures hold only expected outputs.
   python tests/golden/make_classifier_fixtures.py mc       # 64 frames, T=30 all_blocks            (~3 min on 8 AVX-512 cores)
   python tests/golden/make_classifier_fixtures.py 10k      # 10,000 frames, single pass            (~10 min)
   python tests/golden/make_classifier_fixtures.py mfma_mc  # 64 frames, T=30 all_blocks, production bf16-MFMA model (~15 min)
+  python tests/golden/make_classifier_fixtures.py mfma_mc512 # 512 frames (two headline batches), T=30 all_blocks, production model (~1.5-2.5 h; resumes)
   python tests/golden/make_classifier_fixtures.py mfma_10k # 10,000 frames, single pass, production bf16-MFMA model (~1 h; resumes)
   python tests/golden/make_classifier_fixtures.py vit     # ViT-B/16, 64 corrupted frames, production bf16-MFMA model
   python tests/golden/make_classifier_fixtures.py ens5    # BASELINE configs[3]: 5 ResNet-50 members (seeds 1..5), 256 frames, production model (~8 min)
@@ -106,6 +107,29 @@ elif what == "mfma_mc":
                         blob_sha256=info["sha256"],
                         meta="resnet50 seed1; frames seed 21 ids 0..63 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; "
                              "production mode (v_mfma_f32_16x16x32_bf16 model)")
+elif what == "mfma_mc512":
+    # the HEADLINE config on two of its own batches (512 frames, T = 30, all_blocks): per-frame CRC-32 of all 30 x 1000 logits
+    n, T, bs = 512, 30, 4
+    part = os.path.join(HERE, "_mfma_mc512_partial.npz")
+    done = 0
+    labels = np.zeros(n, np.int16); conf = np.zeros(n, np.float32); gaps = np.zeros(n, np.float32); lsum = np.zeros(n, np.uint32)
+    if os.path.exists(part):
+        d = np.load(part)
+        if str(d["blob_sha256"]) == info["sha256"]:
+            done = int(d["done"]); labels, conf, gaps, lsum = d["labels"], d["conf"], d["gap"], d["lsum"]
+    cfg = O.ClassifyConfig(n_samples=T, site_mask=weights.site_mask_for(1, "all_blocks"), p=0.1, seed=4, exact="mfma")
+    t0 = time.time()
+    for s in range(done, n, bs):
+        l, c, lg, pb = O.classify(model, frames(s, bs), cfg, img_ids=np.arange(s, s + bs), return_logits=True)
+        labels[s:s + bs] = l; conf[s:s + bs] = c; gaps[s:s + bs] = gap_of(pb); lsum[s:s + bs] = frame_crc(lg)
+        np.savez(part, done=s + bs, labels=labels, conf=conf, gap=gaps, lsum=lsum, blob_sha256=info["sha256"])
+        print("mfma_mc512", s + bs, round(time.time() - t0, 1), flush=True)
+    np.savez_compressed(os.path.join(HERE, "r50_mfma_mc30_512.npz"), labels=labels, conf=conf, gap=gaps, logit_crc32=lsum,
+                        blob_sha256=info["sha256"],
+                        meta="resnet50 seed1; frames seed 21 ids 0..511 + gaussian noise sev3 seed 3; T=30 all_blocks p=0.1 seed 4; "
+                             "production mode (v_mfma_f32_16x16x32_bf16 model); logit_crc32 = zlib.crc32 of each frame's [30][1000] fp32 logits")
+    if os.path.exists(part):
+        os.remove(part)
 elif what == "mfma_10k":
     # north_star's "label-exact agreement on 10k corrupted test frames" in the arithmetic that ships: the same 10,000
     # frames as the exact-mode fixture through the bit-exact model of v_mfma_f32_16x16x32_bf16
