@@ -308,13 +308,16 @@ bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
     p.H = Ho; p.W = Wo; p.HW = Ho * Wo; p.M = (int)M;
     p.in_W = d.W; p.in_HW = d.H * d.W; p.in_stride = d.stride;
     p.rega_bytes = 0;
+    // [Wc x 2 | bias_b (unused) | bias_c | 256 zero bytes on a 256-byte boundary]
+    p.bias_b_off = 2 * 64 * d.Cin * 2; p.bias_ca_off = p.bias_b_off + d.Cin * 5; p.wa_off0 = p.wa_off1 = p.bias_b_off;
+    p.zero_off = (p.bias_b_off + (d.Cin + d.Cout) * 5 + 255) & ~255;
     p.drop = make_drop(nullptr);
     p.div_hw = fastdiv_make((uint32_t)p.HW);
     p.div_w = fastdiv_make((uint32_t)Wo);
     p.dbg = nullptr;
     const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
     p.g_t1 = G.x; p.g_wc = G.w; p.g_bc = G.b; p.g_y = G.y;
-    const int lds = 2 * 64 * d.Cin * 2 + (d.Cin + d.Cout) * 5 + 16;
+    const int lds = p.zero_off + 256;
     auto kern = bottleneck_tail_kernel<256, 0, false, 2, 4, true, 32, 512, false, false>;
     auto kern_w = bottleneck_tail_kernel<512, 0, false, 2, 8, true, 32, 1024, false, false>;
     static DeviceFlags attr_set;
@@ -486,11 +489,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 
 
 // ---- bottleneck tail (conv_b 3x3 -> conv_c 1x1 + residual + dropout -> next block's conv_a 1x1), one launch ----
-struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2, rp; };
-// Waves per block (pixels per block = 32 * waves).  64 mid channels: 4 waves (128 pixels, two blocks per CU; an 8-wave
-// / 256-pixel variant measured the same, profiles/r2a_tail_bench.txt); 128 mid channels: 8 waves (256 pixels, one block
-// per CU); 256 (conv_c alone): 4 waves, two blocks per CU.
-inline int tail_nw(int cmid) { return cmid == 128 ? 8 : 4; }
+struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2, rp, bias_b_off, bias_ca_off, wa_off0, wa_off1, zero_off; };
 // 512 mid channels (layer 4): the expanding 1x1 + residual + dropout on the row-owning structure.  FAV_TAIL_L4=0 disables.
 bool tail_l4() {
     static const int on = [] { const char* e = getenv("FAV_TAIL_L4"); return e ? atoi(e) : 1; }();
@@ -498,13 +497,21 @@ bool tail_l4() {
 }
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
+    const int cout = 4 * cmid;
+    // default plan behind the weight buffers: bias_b | bias_c | bias_a | 256 zero bytes on a 256-byte boundary
+    auto finish = [&](int bias_b_off, int wa_off0, int wa_bytes) {
+        g->bias_b_off = bias_b_off; g->bias_ca_off = bias_b_off + cmid * 5;
+        g->wa_off0 = wa_off0; g->wa_off1 = wa_off0 + wa_bytes;
+        g->zero_off = (bias_b_off + (cmid + cout + nred) * 5 + 255) & ~255;
+        g->lds_bytes = g->zero_off + 256;
+    };
     // 256 mid channels (layer 3): the expanding 1x1 alone, or with the next block's reduce (then 8 waves x 16 rows)
     if (cmid == 512) {      // layer 4: the expanding 1x1 alone
         if (has3x3 || nred != 0) return false;
         // 8 waves x 32 pixels, Wc double-buffered (2 x 64 KB), one block per CU: 1.14 ms against 1.24 ms for 4 waves with a
         // single Wc buffer at two blocks per CU and 1.27 ms for the generic kernel (profiles/r2j_tail_l4.txt)
         g->patch_bytes = 0; g->rega_bytes = 0; g->nw = 8; g->rp = 32; g->wc2 = 1;
-        g->lds_bytes = 2 * 65536 + (cmid + 4 * cmid) * 5 + 512;
+        finish(2 * 65536, 2 * 65536, 0);
         return true;
     }
     else if (cmid == 256) { if ((has3x3 && nred != 0) || !(nred == 0 || nred == 256)) return false; }
@@ -512,29 +519,37 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
     if (cmid == 256 && has3x3) {
         // conv_b as the generic 256 x 256 x 64 loop (two 64 KB stages); T2, then the Wc buffers, reuse those 128 KB
         g->patch_bytes = 0; g->rega_bytes = 128 * 1024; g->nw = 8; g->rp = 32; g->wc2 = 1;
-        g->lds_bytes = g->rega_bytes + (cmid + 4 * cmid) * 5 + 512;
+        finish(g->rega_bytes, g->rega_bytes, 0);
         return true;
     }
     const int rp = (cmid == 256 && nred == 256) ? 16 : 32;
-    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2, nw = (cmid == 256 && nred == 256) ? 8 : tail_nw(cmid), bm = rp * nw;
-    const int patch = has3x3 ? (int)((((long long)(bm + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
-    // region A: patch | T2 tile | Y chunk; without conv_b the T2 fragments come straight from global memory
-    int rega = has3x3 ? std::max(std::max(patch, bm * 128), bm * rowb) : (nred > 0 ? bm * 128 : 0);
-    rega = (rega + 1023) / 1024 * 1024;
-    const int tail = (cmid + 4 * cmid + nred) * 5 + 512;    // biases + 256 zero bytes on a 256-byte boundary
-    // Wc double-buffered when two blocks still fit a CU (4-wave blocks) / the block fits at all (8-wave blocks)
-    const int ring = has3x3 ? ns * cmid * 128 : 0;
-    const int budget = nw == 4 ? 80 * 1024 : 160 * 1024;
-    int wc2 = 1;
-    int regb = std::max(ring, 2 * 64 * rowb + 2 * nred * 128);
-    if (rega + regb + tail > budget) { wc2 = 0; regb = std::max(ring, 64 * rowb + 2 * nred * 128); }
-    g->patch_bytes = patch;
-    g->rega_bytes = rega;
-    g->nw = nw;
-    g->rp = rp;
-    g->wc2 = wc2;
-    g->lds_bytes = rega + regb + tail;
-    return g->lds_bytes <= 160 * 1024;
+    const int rowb = cmid * 2, ns = cmid == 64 ? 3 : 2;
+    const int wc_bytes = 64 * rowb, wa_bytes = nred * 128;
+    auto plan = [&](int nw) {
+        const int bm = rp * nw;
+        const int patch = has3x3 ? (int)((((long long)(bm + 2 * W + 2) * rowb) + 1023) / 1024 * 1024) : 0;
+        // region A: patch | T2 tile | Y chunk; without conv_b the T2 fragments come straight from global memory
+        int rega = has3x3 ? std::max(std::max(patch, bm * 128), bm * rowb) : (nred > 0 ? bm * 128 : 0);
+        rega = (rega + 1023) / 1024 * 1024;
+        const int ring = has3x3 ? ns * cmid * 128 : 0;
+        const int budget = nw == 4 ? 80 * 1024 : 160 * 1024;
+        g->patch_bytes = patch; g->rega_bytes = rega; g->nw = nw; g->rp = rp;
+        // Wc double-buffered when two blocks still fit a CU (4-wave blocks) / the block fits at all (8-wave blocks)
+        g->wc2 = 1;
+        int regb = std::max(ring, 2 * wc_bytes + 2 * wa_bytes);
+        finish(rega + regb, rega + 2 * wc_bytes, wa_bytes);
+        if (g->lds_bytes > budget) {
+            g->wc2 = 0;
+            regb = std::max(ring, wc_bytes + 2 * wa_bytes);
+            finish(rega + regb, rega + wc_bytes, wa_bytes);
+        }
+        return g->lds_bytes <= budget;
+    };
+    // Waves per block (pixels per block = 32 * waves).  64 mid channels: 4 waves (128 pixels, two blocks per CU; an 8-wave / 256-pixel
+    // variant measured the same, profiles/r2a_tail_bench.txt); 128 mid channels: 8 waves (256 pixels, one block per CU; 4-wave blocks
+    // at two per CU - 81 920 B each with a compact LDS plan - are bit-identical and within 1 %: profiles/r4d_l2_tail_two_blocks_per_cu.txt);
+    // 256 (conv_c alone): 4 waves, two blocks per CU.
+    return plan((cmid == 128 || (cmid == 256 && nred == 256)) ? 8 : 4);
 }
 
 bool tail_wide() {
@@ -575,6 +590,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     p.H = d.H; p.W = d.W; p.HW = d.H * d.W; p.M = (int)M;
     p.in_W = d.W; p.in_HW = p.HW; p.in_stride = 1;
     p.rega_bytes = g.rega_bytes;
+    p.bias_b_off = g.bias_b_off; p.bias_ca_off = g.bias_ca_off; p.wa_off0 = g.wa_off0; p.wa_off1 = g.wa_off1; p.zero_off = g.zero_off;
     p.drop = make_drop(&d.drop);
     p.div_hw = fastdiv_make((uint32_t)p.HW);
     p.div_w = fastdiv_make((uint32_t)d.W);
@@ -613,11 +629,13 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
         unsigned long long lo = ~0ull, hi = 0;
         double ph[5] = {0, 0, 0, 0, 0};
         double cy[5] = {0, 0, 0, 0, 0};   // chunk 1 of wave 0, shader clocks: step A | epilogue | step C | DMA wait | barrier
+        double cz[3] = {0, 0, 0};         // ... residual wait at the top of the chunk | requests for the next chunk | the whole chunk (top of 1 to top of 2)
         for (long long i = 0; i < nblocks; ++i) {
             lo = std::min(lo, t[i * 16]); hi = std::max(hi, t[i * 16 + 5]);
             unsigned long long prev = t[i * 16];
             for (int j = 0; j < 5; ++j) { const unsigned long long c = t[i * 16 + j + 1] ? t[i * 16 + j + 1] : prev; ph[j] += (double)(c - prev); prev = c; }
             for (int j = 0; j < 5; ++j) cy[j] += (double)(t[i * 16 + 7 + j] - t[i * 16 + 6 + j]);
+            cz[0] += (double)(t[i * 16 + 13] - t[i * 16 + 12]); cz[1] += (double)(t[i * 16 + 6] - t[i * 16 + 13]); cz[2] += (double)(t[i * 16 + 14] - t[i * 16 + 12]);
         }
         const double span = (double)(hi - lo), life = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
         fprintf(stderr, "[tail dbg] blocks %lld x %d px, Cmid %d Nred %d 3x3 %d: span %.1f us; per block: patch wait %.2f us, 3x3 loop %.2f us, "
@@ -626,6 +644,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
                 ph[4] / nblocks / 100.0, life / span / 256.0);
         fprintf(stderr, "[tail dbg]   chunk 1, wave 0, shader clocks: step A %.0f, epilogue %.0f, step C %.0f, DMA wait %.0f, barrier %.0f\n",
                 cy[0] / nblocks, cy[1] / nblocks, cy[2] / nblocks, cy[3] / nblocks, cy[4] / nblocks);
+        fprintf(stderr, "[tail dbg]   ... residual wait %.0f, next chunk's requests %.0f, whole chunk 1 %.0f\n", cz[0] / nblocks, cz[1] / nblocks, cz[2] / nblocks);
     };
 #define FAV_TAIL(CMID_, NRED_, H3_, NS_, NW_, WC2_)                                                                   \
     do {                                                                                                              \

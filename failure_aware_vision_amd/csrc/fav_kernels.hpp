@@ -1370,6 +1370,9 @@ struct TailParams {
     int H, W, HW, M;           // OUTPUT frame geometry (= input geometry unless in_stride > 1)
     int in_W, in_HW, in_stride; // conv_c alone as a strided 1x1 (a downsample convolution): input row pitch, frame size, stride
     int rega_bytes;           // LDS region A: patch | T2 tile | Y chunk
+    // The LDS plan is the launcher's (fav.hip: tail_geometry); byte offsets from the block's LDS base: bias_b, then bias_c and bias_a
+    // (16-channel chunks 20 floats apart), the two Wa chunk buffers (chunk j reads buffer (j + 1) & 1), 256 zero bytes on a 256-byte boundary
+    int bias_b_off, bias_ca_off, wa_off0, wa_off1, zero_off;
     DropParams drop;
     FastDiv div_hw, div_w;
     unsigned long long* dbg;  // FAV_CONV_DBG: per-block phase timestamps (null in normal runs)
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     constexpr int WC_PW = (WC_PIECES + NW - 1) / NW, WA_PW = (WA_PIECES + NW - 1) / NW;   // pieces per wave (the last may be skipped)
     static_assert(BR >= 1 && TN1 >= 1 && TM2 >= 1 && WC_PIECES % NW == 0 && (NRED == 0 || WA_PIECES % NW == 0), "tile shape");
     static_assert(!HAS3X3 || (NKT % NS == 0 && WC_BYTES <= SLOT), "Wc buffer 0 = ring slot 0, free during the last NS - 1 steps");
-    constexpr bool WA0_EARLY = !HAS3X3 || WCN * WC_BYTES + WA_BYTES >= RING;   // chunk 0's Wa buffer lies beyond the P1 ring
+    const bool WA0_EARLY = !HAS3X3 || p.wa_off1 >= p.rega_bytes + RING;        // chunk 0's Wa buffer lies beyond the P1 ring (uniform)
     // 256 mid channels: the patch of a 256-pixel tile would not fit, so conv_b runs as the generic 256 x 256 x 64 loop
     // (BOTH operands DMA'd per K tile, two stages = 128 KB); T2 then takes that same 128 KB, and once its fragments
     // sit in registers the Wc buffers of P2 reuse it from offset 0 (no region B, no Y chunk: NRED = 0)
@@ -1466,11 +1469,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     // [region A | region B: weight ring (P1) / Wc x2, Wa x2 (P2) | biases (16-channel chunks 20 floats apart) | 16 zero bytes]
     unsigned char* const ych = tsm;                                // P2: Y chunk [BM][64] bf16, chunk ^= row & 7
     unsigned char* const regb = P1G ? tsm : tsm + p.rega_bytes;
-    const int bias_off = p.rega_bytes + (P1G ? 0 : REGB);
-    float* const bias_b_s = (float*)(tsm + bias_off);
-    float* const bias_c_s = bias_b_s + (CMID / 16) * 20;
+    float* const bias_b_s = (float*)(tsm + p.bias_b_off);
+    float* const bias_c_s = (float*)(tsm + p.bias_ca_off);
     float* const bias_a_s = bias_c_s + (COUT / 16) * 20;
-    const uint32_t zero_off = ((uint32_t)(bias_off + (CMID + COUT + NRED) * 5) + 255u) & ~255u;   // 256 zero bytes, see conv3x3_halo_kernel
+    const uint32_t zero_off = (uint32_t)p.zero_off;                // 256 zero bytes, see conv3x3_halo_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN1, wn = wave % WN1;
@@ -1506,19 +1508,21 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     for (int k = 0; k < NBC; ++k) bias_v[NBB + k] = (tid + k * NT < COUT) ? p.bias_c[tid + k * NT] : 0.f;
 #pragma unroll
     for (int k = 0; k < NBA; ++k) bias_v[NBB + NBC + k] = (tid + k * NT < NRED) ? p.bias_a[tid + k * NT] : 0.f;
-#define FAV_T_BIAS_TO_LDS()                                                                                       \
+#define FAV_T_BIAS_TO_LDS(DO_B, DO_CA)                                                                            \
     do {                                                                                                          \
-        _Pragma("unroll") for (int k = 0; k < NBB; ++k) {                                                         \
+        if (DO_B) _Pragma("unroll") for (int k = 0; k < NBB; ++k) {                                               \
             const int i = tid + k * NT;                                                                           \
             if (i < CMID) bias_b_s[(i >> 4) * 20 + (i & 15)] = bias_v[k];                                         \
         }                                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < NBC; ++k) {                                                         \
-            const int i = tid + k * NT;                                                                           \
-            if (i < COUT) bias_c_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + k];                                   \
-        }                                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < NBA; ++k) {                                                         \
-            const int i = tid + k * NT;                                                                           \
-            if (i < NRED) bias_a_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + NBC + k];                             \
+        if (DO_CA) {                                                                                              \
+            _Pragma("unroll") for (int k = 0; k < NBC; ++k) {                                                     \
+                const int i = tid + k * NT;                                                                       \
+                if (i < COUT) bias_c_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + k];                               \
+            }                                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < NBA; ++k) {                                                     \
+                const int i = tid + k * NT;                                                                       \
+                if (i < NRED) bias_a_s[(i >> 4) * 20 + (i & 15)] = bias_v[NBB + NBC + k];                         \
+            }                                                                                                     \
         }                                                                                                         \
     } while (0)
     if (tid < 64) ((uint32_t*)(tsm + zero_off))[tid] = 0u;
@@ -1570,7 +1574,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         _Pragma("unroll") for (int i = 0; i < WA_PW; ++i) {                                                      \
             const int pc = wave_u + i * NW;                                                                      \
             lds_dma16(srd_wa, (uint32_t)((tail_row_perm(pc * 8 + wrow) * COUT + wch * 8) * 2), (uint32_t)((J) * 128), \
-                      __builtin_amdgcn_readfirstlane(lds_regb + (uint32_t)(WCN * WC_BYTES + (((J) + 1) & 1) * WA_BYTES + pc * 1024))); \
+                      __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(((((J) + 1) & 1) ? p.wa_off1 : p.wa_off0) + pc * 1024))); \
         }                                                                                                        \
     } while (0)
 
@@ -1628,7 +1632,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         }                                                                                                        \
     } while (0)
             FAV_T_GSTAGE(0, 0);
-            FAV_T_BIAS_TO_LDS();
+            FAV_T_BIAS_TO_LDS(true, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
@@ -1714,7 +1718,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             }
             tapmask[b] = mk;
         }
-        FAV_T_BIAS_TO_LDS();
+        FAV_T_BIAS_TO_LDS(true, true);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
         __syncthreads();
         if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
@@ -1825,7 +1829,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 t2f[b][ks] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
-        FAV_T_BIAS_TO_LDS();
+        FAV_T_BIAS_TO_LDS(true, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights (and the fragments)
         __syncthreads();
     }
@@ -1857,9 +1861,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 #pragma unroll
     for (int j = 0; j < NCHUNK; ++j) {
         const unsigned char* const wcb = regb + (j % WCN) * WC_BYTES;
-        const unsigned char* const wab = regb + WCN * WC_BYTES + ((j + 1) & 1) * WA_BYTES;
+        const unsigned char* const wab = tsm + (((j + 1) & 1) ? p.wa_off1 : p.wa_off0);
         // residual of THIS chunk has landed; then the requests of the NEXT chunk (the other weight buffers: every
         // wave is past chunk j-1, the barrier at its end says so)
+        if ((j == 1 || j == 2) && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + (j == 1 ? 12 : 14)] = __builtin_amdgcn_s_memtime();
         if (HAS_RES) {
 #pragma unroll
             for (int b = 0; b < TM2; ++b) {
@@ -1868,6 +1873,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 rcur[b][1] = rnext[b][1];
             }
         }
+        if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(rcur[TM2 - 1][1])); p.dbg[blockIdx.x * 16ull + 13] = __builtin_amdgcn_s_memtime(); }
         if (j + 1 < NCHUNK) {
             if (BARQ == 2) {
                 if ((j & 1) == 0 && j + 2 < NCHUNK) { FAV_T_STAGE_WC(j + 2); FAV_T_STAGE_WC(j + 3); }
