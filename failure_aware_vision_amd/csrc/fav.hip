@@ -607,8 +607,9 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     }
     const int cmid = d.Cmid, cout = 4 * cmid;
     const double flops = 2.0 * (double)M * ((has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
-    // res_entry: the residual is the cached tensor (read once per sample it is needed for; counted as the rows it serves, like a stored residual)
-    const double bytes = 2.0 * ((double)M * (cmid + 2.0 * cout + nred) + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
+    // res_entry: the residual is the cached tensor [n_img][HW][cout], counted ONCE (every sample's tile re-reads it, from L2), not once per row it serves
+    const double res_rows = d.res_entry ? (double)std::min<long long>(d.n_frames, p.drop.n_img) * p.HW : (double)M;
+    const double bytes = 2.0 * ((double)M * (cmid + 1.0 * cout + nred) + res_rows * cout + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
     { static const int lds_pad = [] { const char* e = getenv("FAV_TAIL_LDS_PAD"); return e ? atoi(e) : 0; }(); if (g.lds_bytes + lds_pad <= 160 * 1024) g.lds_bytes += lds_pad; }   // experiments: fewer blocks per CU
     const int bm = g.rp * g.nw;
@@ -826,7 +827,9 @@ const char* launch_entry_reduce(fav_handle* h, const void* x, void* y, const voi
     const long long cached = std::min<long long>(dp.n_img, n_out);
     const double rows = (double)n_out * HW;
     Prof pr(h, s, FAV_K_CONV, 2.0 * rows * C * nred, 2.0 * ((double)cached * HW * C + rows * ((y ? C : 0) + nred) + (double)C * nred));
-    hipLaunchKernelGGL((entry_reduce_kernel<256, 64>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
+    static const int occ = [] { const char* e = getenv("FAV_ENTRY_OCC"); return e ? atoi(e) : 3; }();
+    if (occ == 2) hipLaunchKernelGGL((entry_reduce_kernel<256, 64, 2>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((entry_reduce_kernel<256, 64, 3>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
     return nullptr;
 }
 
@@ -868,17 +871,20 @@ const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, i
     const int lds = nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride;
     static DeviceFlags attr_set;
     if (!attr_set.test_current()) {
-        if (hipFuncSetAttribute((const void*)attention_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attention_kernel<0, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attention_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attention_kernel<1, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attention_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return "attention: cannot reserve LDS";
         attr_set.set_current();
     }
     const double flops = 4.0 * n * heads * (double)T * T * 64;
     Prof pr(h, s, FAV_K_CONV, flops, (double)n * T * D * 2 * 4);
-    if (math_mode == FAV_MATH_BF16)
-        hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)(n * heads)), dim3(nw * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
-    else
-        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)(n * heads)), dim3(nw * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads);
+    const dim3 grid((unsigned)(n * heads)), block(nw * 64);
+#define FAV_ATTN(MODE_, NKT_) hipLaunchKernelGGL((attention_kernel<MODE_, NKT_>), grid, block, lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads)
+    if (math_mode == FAV_MATH_BF16) { if (nkt <= 13) FAV_ATTN(0, 13); else FAV_ATTN(0, 16); }
+    else { if (nkt <= 13) FAV_ATTN(1, 13); else FAV_ATTN(1, 16); }
+#undef FAV_ATTN
     return nullptr;
 }
 

@@ -2202,8 +2202,8 @@ struct EntryReduceParams {
     FastDiv div_hw;
 };
 
-template <int C, int NRED>
-__global__ __launch_bounds__(256, 3) void entry_reduce_kernel(const EntryReduceParams p) {
+template <int C, int NRED, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void entry_reduce_kernel(const EntryReduceParams p) {
     constexpr int NW = 4, BM = 32 * NW, TM2 = 2, NJ = C / 64, NA3 = NRED / 16, G3 = NRED / 64;
     constexpr int WA_BYTES = NRED * 128;                  // one 64-k chunk of Wa: NRED rows x 128 B
     constexpr int WA_PW = WA_BYTES / 1024 / NW;           // LDS-DMA pieces per wave per chunk
@@ -2436,7 +2436,9 @@ typedef short attn_v4s __attribute__((ext_vector_type(4)));
 // (rows r .. r+3 and r+8 .. r+11 of one 16-channel column pair) fall on 64 different banks; even, so a pair stays a pair
 __device__ __forceinline__ int attn_vsw(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
 
-template <int MODE>
+// NKT = key tiles the kernel is built for (T <= 16 NKT): 13 for ViT-B/16's 197 tokens - 12 score registers fewer than 16, which is
+// what keeps the 16-wave block (128 registers per wave) free of scratch.
+template <int MODE, int NKT = 16>
 __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
                                                          int heads) {
     extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
@@ -2499,9 +2501,9 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
                 if (q < T) fqv[kk] = *(const uint4*)(base + (long long)q * 3 * D + h * 64 + kk * 32 + fq * 8);
             }
         }
-        f32x4_t sc[16];
+        f32x4_t sc[NKT];
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
             sc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             if (kt < nkt) {
 #pragma unroll
@@ -2527,7 +2529,7 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
         // scale, mask, row max
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -2541,7 +2543,7 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -2554,7 +2556,7 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
         sum = __fadd_rn(sum, __shfl_xor(sum, 32, 64));
         const float inv_sum = __fdiv_rn(1.0f, sum);   // one IEEE division per query row, then multiplications
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
                 const float p0 = __fmul_rn(sc[kt][0], inv_sum), p1 = __fmul_rn(sc[kt][1], inv_sum);
                 const float p2 = __fmul_rn(sc[kt][2], inv_sum), p3 = __fmul_rn(sc[kt][3], inv_sum);

@@ -36,7 +36,7 @@ def conv_sum(sub, counter):
     tot, n = 0.0, 0
     if f:
         for row in csv.DictReader(open(f)):
-            if any(k in row["Kernel_Name"] for k in ("conv_igemm_kernel", "conv3x3_halo_kernel", "bottleneck_tail_kernel", "entry_reduce_kernel")) and row["Counter_Name"] == counter:
+            if any(k in row["Kernel_Name"] for k in ("conv_igemm_kernel", "conv3x3_halo_kernel", "bottleneck_tail_kernel", "entry_reduce_kernel", "stem7_pool_kernel")) and row["Counter_Name"] == counter:
                 tot += float(row["Counter_Value"]); n += 1
     return tot, n
 fs, fn = conv_sum("pmc_fetch", "FETCH_SIZE")
