@@ -827,9 +827,7 @@ const char* launch_entry_reduce(fav_handle* h, const void* x, void* y, const voi
     const long long cached = std::min<long long>(dp.n_img, n_out);
     const double rows = (double)n_out * HW;
     Prof pr(h, s, FAV_K_CONV, 2.0 * rows * C * nred, 2.0 * ((double)cached * HW * C + rows * ((y ? C : 0) + nred) + (double)C * nred));
-    static const int occ = [] { const char* e = getenv("FAV_ENTRY_OCC"); return e ? atoi(e) : 3; }();
-    if (occ == 2) hipLaunchKernelGGL((entry_reduce_kernel<256, 64, 2>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((entry_reduce_kernel<256, 64, 3>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((entry_reduce_kernel<256, 64>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), 0, s, p);
     return nullptr;
 }
 

@@ -2202,8 +2202,10 @@ struct EntryReduceParams {
     FastDiv div_hw;
 };
 
-template <int C, int NRED, int OCC = 3>
-__global__ __launch_bounds__(256, OCC) void entry_reduce_kernel(const EntryReduceParams p) {
+// Two blocks per CU: under __launch_bounds__(256, 3) the 64 cached-pixel registers + 32 accumulators + one Philox call spilled 21
+// registers into the sample loop (1.93 -> 1.72 ms per headline step without them, profiles/r4f_entry_occupancy_ab.txt).
+template <int C, int NRED>
+__global__ __launch_bounds__(256, 2) void entry_reduce_kernel(const EntryReduceParams p) {
     constexpr int NW = 4, BM = 32 * NW, TM2 = 2, NJ = C / 64, NA3 = NRED / 16, G3 = NRED / 64;
     constexpr int WA_BYTES = NRED * 128;                  // one 64-k chunk of Wa: NRED rows x 128 B
     constexpr int WA_PW = WA_BYTES / 1024 / NW;           // LDS-DMA pieces per wave per chunk
