@@ -48,6 +48,11 @@ class FavConvDesc(C.Structure):
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("math_mode", C.c_int32), ("drop", FavDropoutDesc)]
 
 
+class FavLinearDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+                ("rows", C.c_int64), ("K", C.c_int32), ("N", C.c_int32), ("act", C.c_int32)]
+
+
 class FavTailDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wb", C.c_void_p), ("bias_b", C.c_void_p), ("wc", C.c_void_p), ("bias_c", C.c_void_p),
                 ("res", C.c_void_p), ("y", C.c_void_p), ("wa", C.c_void_p), ("bias_a", C.c_void_p), ("t1n", C.c_void_p),
@@ -90,6 +95,7 @@ _SIGNATURES = {
     "fav_get_op_profile": (C.c_int, [C.c_void_p, C.POINTER(FavOpProfile), C.c_int32, C.POINTER(C.c_int32)]),
     "fav_op_conv2d": (C.c_int, [C.POINTER(FavConvDesc), C.c_void_p]),
     "fav_op_bottleneck_tail": (C.c_int, [C.POINTER(FavTailDesc), C.c_void_p]),
+    "fav_op_linear_streamk": (C.c_int, [C.POINTER(FavLinearDesc), C.c_void_p]),
     "fav_op_stem_im2col": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.c_void_p, C.c_void_p]),

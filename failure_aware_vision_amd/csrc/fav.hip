@@ -152,6 +152,10 @@ struct fav_handle {
     int group_max_frames = 0;
     std::vector<hipStream_t> vit_streams;   // ViT: parts of the batch side by side
     std::vector<hipEvent_t> vit_done;
+    // chained stream-K GEMM (gemm_streamk_kernel): one workspace per stream the encoder may run on (slot 0: the caller's)
+    struct SkWs { float* ws = nullptr; uint32_t* flags = nullptr; uint32_t* err = nullptr; uint32_t epoch = 0; int grid_cap = 0; };
+    SkWs sk[5];
+    int sk_slot = 0;                        // the slot run_vit's launches use
     bool plan_no_fuse = false;      // fav_plan_schedule: build the layer-by-layer schedule (the fused one's reference)
     std::vector<void*> phase_out;   // output tensor of each phase
     float* logits = nullptr;        // [T][max_batch][cpad]
@@ -858,6 +862,93 @@ const char* launch_layernorm(fav_handle* h, const void* x, long long ldx, const 
     return nullptr;
 }
 
+// ---- chained stream-K GEMM (gemm_streamk_kernel): the ViT encoder's linear layers -----------------------------------------------
+// Returns false when the shape is not the kernel's (the caller then takes the tile-per-block kernel: same bits).
+// The grid is k x CUs workgroups, k = 3, 2 or 1: the largest for which every XCD group's share of the tiles is >= its workgroups,
+// i.e. every workgroup's share of K steps is at least one whole tile (a workgroup then publishes at most one partial accumulator,
+// at its start, and takes over at most one, at its end).
+struct SkDevice { fav_handle::SkWs ws; int device = -1; };
+bool sk_prepare(fav_handle::SkWs* w, int grid) {
+    if (w->grid_cap >= grid) return true;
+    if (w->ws) { (void)hipFree(w->ws); (void)hipFree(w->flags); (void)hipFree(w->err); w->ws = nullptr; }
+    const int cap = std::max(grid, 768);
+    if (hipMalloc((void**)&w->ws, (size_t)cap * 65536) != hipSuccess || hipMalloc((void**)&w->flags, (size_t)cap * 4) != hipSuccess ||
+        hipMalloc((void**)&w->err, 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemset(w->flags, 0, (size_t)cap * 4) != hipSuccess || hipMemset(w->err, 0, 4) != hipSuccess) return false;
+    w->grid_cap = cap;
+    w->epoch = 0;
+    return true;
+}
+// Off by default: bit-identical to the tile-per-block kernel but slower at the encoder's shapes on this part (profiles/r4g_streamk_*:
+// the hand-offs' agent-scope fences and 2 x 64 KB per workgroup cost ~25 % of a launch, and shares that start at different K steps
+// lose the lock step that keeps the tile kernel's LDS-DMA stream in the XCD's 4 MB L2).  FAV_STREAMK=1 routes the encoder through it.
+bool streamk_enabled() {
+    static const int on = [] { const char* e = getenv("FAV_STREAMK"); return e ? atoi(e) : 0; }();
+    return on != 0;
+}
+bool launch_gemm_streamk(fav_handle* h, const void* a, const void* w, const float* bias, const void* res, void* y, long long M, int K, int N,
+                         int act, hipStream_t s) {
+    if ((h && !streamk_enabled()) || M < 1 || K % 32 != 0 || K < 128 || N % 128 != 0 || act < 0 || act > 2) return false;
+    const long long tiles_m = (M + 127) / 128;
+    const long long tiles = tiles_m * (N / 128);
+    if ((double)(M + 128) * std::max(N, K) * 2.0 >= 2147483647.0 || (double)N * K * 2.0 >= 2147483647.0 || tiles > 0x3fffffffLL) return false;
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false; n_cu = prop.multiProcessorCount; }
+    int per_cu = 0;
+    for (int k = 3; k >= 1; --k)
+        if (tiles / 8 >= (long long)(n_cu * k) / 8) { per_cu = k; break; }
+    if (!per_cu || (n_cu * per_cu) % 8 != 0) return false;
+    const int grid = n_cu * per_cu;
+    static SkDevice op_ws[16];               // op-level calls (no handle): one workspace per device, kept for the life of the process
+    fav_handle::SkWs* W;
+    if (h) W = &h->sk[h->sk_slot];
+    else { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false; W = &op_ws[dev].ws; }
+    if (!sk_prepare(W, grid)) return false;
+    GemmSkParams p;
+    memset(&p, 0, sizeof p);
+    p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.bias = bias; p.res = (const uint16_t*)res; p.y = (uint16_t*)y;
+    p.M = (int)M; p.N = N; p.K = K; p.ksteps = K / 32;
+    p.tiles_n = N / 128; p.tiles = (int)tiles;
+    p.act = act;
+    { static const bool nohand = getenv("FAV_SK_NOHANDOFF") != nullptr; if (nohand) p.act |= 0x100; }   // TIMING ONLY (wrong results): what the hand-offs cost
+    p.Q = grid / 8;
+    p.ws = W->ws; p.flags = W->flags; p.err = W->err;
+    p.epoch = ++W->epoch;
+    if (p.epoch == 0) { (void)hipMemsetAsync(W->flags, 0, (size_t)W->grid_cap * 4, s); p.epoch = W->epoch = 1; }
+    p.div_tn = fastdiv_make((uint32_t)p.tiles_n);
+    const double flops = 2.0 * (double)M * N * K;
+    const double bytes = 2.0 * ((double)M * K + (double)M * N * (res ? 2 : 1) + (double)N * K);
+    Prof pr(h, s, FAV_K_CONV, flops, bytes);
+    // dynamic LDS the kernel never touches: it makes per_cu workgroups - not more - fit a CU beside the kernel's own 53 248 B, so the
+    // smaller grids sit two / one per CU instead of three on some CUs and none on others
+    const int pad_lds = per_cu == 3 ? 0 : (per_cu == 2 ? 26 * 1024 : 104 * 1024);
+    static DeviceFlags attr_set;
+    if (!attr_set.test_current()) {
+        if (hipFuncSetAttribute((const void*)gemm_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+        attr_set.set_current();
+    }
+    static const bool dbg_on = getenv("FAV_SK_DBG") != nullptr;   // experiments only: where a step's ticks go
+    if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)grid * 64); (void)hipMemset(p.dbg, 0, (size_t)grid * 64); }
+    hipLaunchKernelGGL(gemm_streamk_kernel, dim3((unsigned)grid), dim3(256), pad_lds, s, p);
+    if (p.dbg) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> t((size_t)grid * 8);
+        (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(p.dbg);
+        double ph[5] = {0, 0, 0, 0, 0}, steps = 0;
+        unsigned long long lo = ~0ull, hi = 0; double life = 0;
+        for (int i = 0; i < grid; ++i) {
+            for (int k = 0; k < 5; ++k) ph[k] += (double)t[i * 8 + k];
+            steps += (double)t[i * 8 + 5];
+            lo = std::min(lo, t[i * 8 + 6]); hi = std::max(hi, t[i * 8 + 7]); life += (double)(t[i * 8 + 7] - t[i * 8 + 6]);
+        }
+        fprintf(stderr, "[sk dbg] span %.1f us, mean workgroup life %.1f us, resident workgroups per CU %.2f\n", (hi - lo) / 100.0, life / grid / 100.0, life / (double)(hi - lo) / n_cu);
+        fprintf(stderr, "[sk dbg] M %lld K %d N %d grid %d: %.1f steps per workgroup; ticks per step (wave 0): stage %.0f, reads + MFMAs %.0f, segment end %.0f, "
+                        "vmcnt wait %.0f, barrier %.0f\n", M, K, N, grid, steps / grid, ph[0] / steps, ph[1] / steps, ph[2] / steps, ph[3] / steps, ph[4] / steps);
+    }
+    return true;
+}
+
 const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, int T, int D, int heads, int math_mode, hipStream_t s) {
     if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
     const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
@@ -1460,6 +1551,7 @@ void free_all(fav_handle* h) {
         if (w.done) (void)hipEventDestroy(w.done);
     }
     if (h->ev_members) (void)hipEventDestroy(h->ev_members);
+    for (auto& w_ : h->sk) if (w_.ws) { (void)hipFree(w_.ws); (void)hipFree(w_.flags); (void)hipFree(w_.err); }
     for (auto st_ : h->vit_streams) (void)hipStreamDestroy(st_);
     for (auto ev_ : h->vit_done) (void)hipEventDestroy(ev_);
     for (size_t i = 0; i + 1 < h->phase_out.size(); ++i) if (h->phase_out[i]) (void)hipFree(h->phase_out[i]);
@@ -1543,6 +1635,8 @@ fav_status run_vit(fav_handle* h, const void* images_all, int layout, int f0, in
         d.n_frames = n; d.H = rows_per_frame; d.W = 1; d.Cin = L.k; d.Cout = L.cout;
         d.kh = 1; d.kw = 1; d.stride = 1; d.pad = 0; d.relu = act; d.out_f32 = out_f32; d.math_mode = c.math_mode;
         d.drop.site = -1;
+        if (!out_f32 && c.math_mode == FAV_MATH_BF16 && L.cout == L.cout_pad &&
+            launch_gemm_streamk(h, x, L.w, L.b, res, y, (long long)n * rows_per_frame, L.k, L.cout, act, s)) return nullptr;
         return launch_conv(h, d, L.cout_pad, out_f32 ? L.cout_pad : L.cout, s);
     };
 #define FAV_VIT_TRY(expr)                                            \
@@ -1861,12 +1955,14 @@ fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int3
             for (int part = 0; part < vit_streams; ++part) {
                 const int f0 = (int)((long long)n * part / vit_streams), f1 = (int)((long long)n * (part + 1) / vit_streams);
                 HIP_KEEP(h, st, hipStreamWaitEvent(h->vit_streams[part], h->ev_fork, 0));
+                h->sk_slot = 1 + part;
                 if (st == FAV_OK) st = run_vit(h, images, layout, f0, f1 - f0, h->vit_streams[part]);
                 HIP_KEEP(h, st, hipEventRecord(h->vit_done[part], h->vit_streams[part]));
                 HIP_KEEP(h, st, hipStreamWaitEvent(s, h->vit_done[part], 0));
             }
             if (st != FAV_OK) return st;
         } else {
+            h->sk_slot = 0;
             fav_status st = run_vit(h, images, layout, 0, n, s);
             if (st != FAV_OK) return st;
         }
@@ -2128,6 +2224,13 @@ fav_status fav_op_attention(const void* qkv, void* out, int32_t n, int32_t T, in
                             void* stream) {
     if (!qkv || !out) return op_done("fav_op_attention: null pointer");
     return op_done(launch_attention(nullptr, qkv, out, n, T, D, heads, math_mode, (hipStream_t)stream));
+}
+
+fav_status fav_op_linear_streamk(const fav_linear_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->bias || !d->y) return op_done("fav_op_linear_streamk: null pointer");
+    if (!launch_gemm_streamk(nullptr, d->x, d->w, d->bias, d->res, d->y, d->rows, d->K, d->N, d->act, (hipStream_t)stream))
+        return op_done("fav_op_linear_streamk: shape not supported (K % 32, N % 128, >= 256 tiles of 128 x 128, 32-bit offsets)");
+    return op_done(nullptr);
 }
 
 fav_status fav_op_vit_assemble(const void* emb, const float* pos, void* x, int32_t n, int32_t ntok, int32_t D, void* stream) {

@@ -79,7 +79,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
         const unsigned long long p0 = (unsigned long long)M0 * c.x, p1 = (unsigned long long)M1 * c.z;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        // a ^ b ^ c as ONE v_bitop3_b32 (truth table 0x96): gfx950 has no v_xor3, and hipcc leaves the pair of v_xor_b32 alone -
+        // 20 of a call's ~100 vector instructions (headline 75.44 -> 74.73 ms in a same-box A/B, profiles/r4n_philox_bitop3_ab.txt)
+        c = make_uint4(__builtin_amdgcn_bitop3_b32(hi1, c.y, k0, 0x96), lo1, __builtin_amdgcn_bitop3_b32(hi0, c.w, k1, 0x96), lo0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -2342,6 +2344,345 @@ __global__ __launch_bounds__(256, 2) void entry_reduce_kernel(const EntryReduceP
                 }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Chained stream-K GEMM: the ViT encoder's linear layers, Y[m, n] = act((sum_k A[m, k] W[n, k] + bias[n]) + res[m, n]).
+//
+// At the per-GPU share of BASELINE configs[4] (64 frames: M = 12 608 rows) a linear layer is 594 - 2 376 tiles of 128 x 128 on
+// 256 CUs: 2.3 - 9.3 tiles per CU, and the launch ends when the CUs with one tile more than the others finish - 77 % of the chip
+// at 2.32 tiles per CU.  Here the unit of work is one 32-deep K step of one tile, and a persistent grid deals the steps out in
+// equal contiguous shares, so every workgroup does the same number of steps (+- 1) whatever the tile count is.
+//
+// A share that ends inside a tile leaves an fp32 partial accumulator in a workspace slot; the workgroup whose share starts inside
+// that tile LOADS it as its initial accumulator and continues the chain of MFMAs - the sum an output element sees is the one
+// uninterrupted ascending-k chain the tile-per-block kernel runs, so the results are BIT-IDENTICAL to conv_igemm_kernel's (no
+// split-K reordering, no dependence on the grid or on M: every fixture stays).  The chain costs no waiting because a workgroup
+// walks its share BACKWARDS by tile: first the head part of its last tile (published at once), then its whole tiles, and only at
+// the very end the tail part of its first tile, whose head its predecessor published at ITS very start.
+//
+// Placement: blocks b, b + 8, ... share an XCD (observed; speed only).  The tiles are cut into 8 contiguous runs, one per such
+// group, n fastest, and a group's Q = grid / 8 workgroups share the run's steps: neighbours in a group work on the same rows of A
+// (one L2), and a workgroup only ever waits for block b - 8, which is dispatched before it and needs nobody to publish.  The
+// launcher sizes the grid to what is co-resident anyway and keeps shares >= one tile (no workgroup both waits and publishes).
+// Hand-off: plain 16-byte stores, every wave's vmcnt(0), barrier, one lane's agent-scope release + vmcnt(0) + relaxed flag store;
+// the consumer polls relaxed (bounded: gives up into *err), acquires at agent scope, vmcnt(0), barrier, plain loads - the
+// MI355X guide's valid form.  Flags carry the launch's epoch, so nothing is reset between launches.
+//
+// Tile 128 x 128, 4 waves of 64 x 64, 32-deep steps through a three-slot LDS-DMA ring that never drains: the steps of the next
+// tile are in flight while this tile's epilogue runs.  Epilogue in registers as conv_igemm_kernel's EPI = 1 (weight rows staged
+// in tail_row_perm-like order: a lane ends up with 16 consecutive channels), the tile's bias arrives by LDS-DMA with its first step.
+// ---------------------------------------------------------------------------
+struct GemmSkParams {
+    const uint16_t* a;        // [M][K] bf16
+    const uint16_t* w;        // [N][K] bf16
+    const float* bias;        // [N]
+    const uint16_t* res;      // [M][N] bf16 or null; may be y (in-place residual: a tile reads its own rows, then writes them)
+    uint16_t* y;              // [M][N] bf16
+    int M, N, K, ksteps;      // ksteps = K / 32
+    int tiles_n, tiles;       // tiles = ceil(M / 128) * (N / 128)
+    int act;                  // 0 none, 2 tanh-form GELU
+    int Q;                    // workgroups per XCD group; grid = 8 Q
+    float* ws;                // [grid][16][256] float4: partial accumulators
+    uint32_t* flags;          // [grid]: == epoch once the slot is published
+    uint32_t epoch;
+    uint32_t* err;            // set to 1 if a consumer gave up waiting
+    FastDiv div_tn;           // / tiles_n
+    unsigned long long* dbg;  // FAV_SK_DBG: per-workgroup sums of s_memtime ticks per loop phase (null in normal runs)
+};
+
+// wait until at most n vector-memory operations of this wave are outstanding (n uniform; one of the counts the kernel produces)
+__device__ __forceinline__ void sk_wait_vmcnt(int n) {
+#define FAV_SKW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
+    switch (n) {
+        FAV_SKW(4) FAV_SKW(5) FAV_SKW(12) FAV_SKW(13) FAV_SKW(20) FAV_SKW(21) FAV_SKW(28) FAV_SKW(29) FAV_SKW(36) FAV_SKW(37)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef FAV_SKW
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_streamk_kernel(const GemmSkParams p) {
+    constexpr int BM = 128, BN = 128, ROWB = 64, STAGE = (BM + BN) * ROWB, A_BYTES = BM * ROWB, NS = 3;
+    constexpr int TM = 4, TN = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + 4 * 1024];   // ring | four bias buffers (128 floats + the piece's zero half):
+                                                                                          // the staging side runs up to two SEGMENTS ahead (a head part may be one step long)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- this workgroup's schedule inside its group's run of tiles [tx0, tx0 + ntx) ------------------------------------------------
+    // The run is walked in rounds of Q consecutive tiles, one tile per workgroup - all workgroups of the group on the same rows of A
+    // and the same K slice at the same time, as a tile-per-block launch has them (dealing the WHOLE run out in contiguous shares
+    // was 2x slower: a share of several tiles walks along n alone, 43 % of its L2 requests missed) - and only the last Q + r tiles
+    // (one round plus the remainder) are dealt out by K steps: shares of 1 .. 2 tiles, [u0, u1) in steps from the region's start.
+    const int wg = blockIdx.x, xg = wg & 7, qg = wg >> 3;
+    const int tq = p.tiles >> 3, tr = p.tiles & 7;
+    const int tx0 = xg * tq + (xg < tr ? xg : tr), ntx = tq + (xg < tr ? 1 : 0);
+    const int ndp = ntx / p.Q - 1;                // whole rounds in front of the stream-K region (the launcher keeps ntx >= Q)
+    if (ndp < 0) return;
+    const int sk0 = ndp * p.Q, nsk = ntx - sk0;   // the region: tiles [sk0, ntx) of the run, Q <= nsk < 2 Q
+    const long long Ug = (long long)nsk * p.ksteps;
+    // (64-bit divisions run on the vector ALUs: back into scalar registers, the LDS-DMA statements take their offsets from there)
+    const int u0 = __builtin_amdgcn_readfirstlane((int)(Ug * qg / p.Q)), u1 = __builtin_amdgcn_readfirstlane((int)(Ug * (qg + 1) / p.Q));
+    const int nsteps = ndp * p.ksteps + (u1 - u0);
+    const int tf = u0 / p.ksteps, k0 = u0 - tf * p.ksteps;                  // first tile of the share (region-local), its first step
+    const int tl = (u1 - 1) / p.ksteps, k1 = u1 - tl * p.ksteps;            // last tile, the step behind its last one (<= ksteps)
+    // segments in processing order: [the rounds' tiles] [head part of the share's last tile] [its whole tiles] [tail part of its
+    // first tile] - the share is walked backwards, so that a partial accumulator is published long before it is wanted
+    const bool one = tf == tl;
+    const int hasH = (one || k1 < p.ksteps) ? 1 : 0;                       // a single-tile share is one segment, filed as "head"
+    const int hasT = (!one && k0 > 0) ? 1 : 0;
+    const int tfull0 = tf + hasT, nfull = one ? 0 : (tl - (k1 < p.ksteps ? 1 : 0)) - tfull0 + 1;
+    const int nseg = ndp + hasH + nfull + hasT;
+    // segment j: run-local tile, steps [ka, kb)
+#define FAV_SK_SEG(J, TILE, KA, KB)                                                   \
+    do {                                                                              \
+        const int j_ = (J) - ndp;                                                     \
+        if (j_ < 0) { TILE = (J) * p.Q + qg; KA = 0; KB = p.ksteps; }                 \
+        else if (hasH && j_ == 0) { TILE = sk0 + tl; KA = one ? k0 : 0; KB = k1; }    \
+        else if (j_ - hasH < nfull) { TILE = sk0 + tfull0 + (j_ - hasH); KA = 0; KB = p.ksteps; } \
+        else { TILE = sk0 + tf; KA = k0; KB = p.ksteps; }                             \
+    } while (0)
+
+    // ---- staging side ----------------------------------------------------------------------------------------------------------
+    // rows of 64 B (32 k), a piece = 16 rows; lane -> row l >> 2, physical 16-B slot l & 3 holds chunk (l & 3) ^ swz(row)
+    const int lrow = lane >> 2, lch = (lane & 3) ^ lds_swz<32>(lrow);
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)((long long)p.M * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.N * 4, 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+    const uint32_t lds_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)smem);
+    const uint32_t lds_a = lds_base + wave_u * 2048, lds_b = lds_base + A_BYTES + wave_u * 2048;
+    uint32_t a_voff[2], b_voff[2], bias_voff = OOB;
+    int pj = 0, ptile = 0, pk = 0, pkb = 0;         // producer cursor: segment, tile, next step to stage, end of the segment
+    bool pfirst = true;                             // the next staged step is the first of its segment
+#define FAV_SK_PTILE()                                                                                           \
+    do {                                                                                                         \
+        const int tg_ = tx0 + ptile;                                                                             \
+        const int tm_ = (int)fastdiv((uint32_t)tg_, p.div_tn), tn_ = tg_ - tm_ * p.tiles_n;                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+            const int ra_ = tm_ * BM + (wave * 2 + i) * 16 + lrow;                                               \
+            a_voff[i] = ra_ < p.M ? (uint32_t)(((long long)ra_ * p.K + lch * 8) * 2) : OOB;                      \
+            int rb_ = (wave * 2 + i) * 16 + lrow;        /* LDS row of the B tile this lane fills -> the weight row it holds */ \
+            rb_ = (rb_ & ~63) + 16 * ((rb_ & 15) >> 2) + 4 * ((rb_ >> 4) & 3) + (rb_ & 3);                       \
+            b_voff[i] = (uint32_t)(((long long)(tn_ * BN + rb_) * p.K + lch * 8) * 2);                           \
+        }                                                                                                        \
+        bias_voff = lane < 32 ? (uint32_t)((tn_ * BN + lane * 4) * 4) : OOB;                                     \
+    } while (0)
+    // stage the producer cursor's step into ring slot SLOT; returns the pieces issued in NP
+#define FAV_SK_STAGE(SLOT, NP)                                                                                   \
+    do {                                                                                                         \
+        const uint32_t soff_ = (uint32_t)(pk * ROWB);                                                            \
+        NP = 4;                                                                                                  \
+        if (pfirst) {                                                                                            \
+            lds_dma16(srd_bias, bias_voff, 0u, __builtin_amdgcn_readfirstlane(lds_base + NS * STAGE + (uint32_t)(pj & 3) * 1024u)); \
+            NP = 5;                                                                                              \
+            pfirst = false;                                                                                      \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            lds_dma16(srd_a, a_voff[i], soff_, __builtin_amdgcn_readfirstlane(lds_a + (uint32_t)(SLOT) * STAGE + i * 1024)); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            lds_dma16(srd_b, b_voff[i], soff_, __builtin_amdgcn_readfirstlane(lds_b + (uint32_t)(SLOT) * STAGE + i * 1024)); \
+        if (++pk == pkb) {                                                                                       \
+            if (++pj < nseg) { FAV_SK_SEG(pj, ptile, pk, pkb); FAV_SK_PTILE(); pfirst = true; }                  \
+        }                                                                                                        \
+    } while (0)
+
+    FAV_SK_SEG(0, ptile, pk, pkb);
+    FAV_SK_PTILE();
+
+    // ---- consumer side ---------------------------------------------------------------------------------------------------------
+    int cj = 0, ctile = 0, ck = 0, ckb = 0;
+    FAV_SK_SEG(0, ctile, ck, ckb);
+    bool cfirst = true;
+    f32x4_t acc[TN][TM];
+    u32x4_t rr[TM][2];                               // residual of the current tile: 16 channels of 4 pixel rows
+    const __amdgpu_buffer_rsrc_t srd_res = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.res ? (int)((long long)p.M * p.N * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((long long)p.M * p.N * 2), 0x00020000);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) rr[b][0] = rr[b][1] = (u32x4_t){0u, 0u, 0u, 0u};
+
+    int np0, np1;
+    FAV_SK_STAGE(0, np0);
+    np1 = 0;
+    if (nsteps > 1) FAV_SK_STAGE(1, np1);
+    sk_wait_vmcnt(np1);                              // step 0 has landed (np1 = 0: everything)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int e_prev = 0;                                  // vector-memory operations issued in the previous iteration behind its stage
+    int slot = 0;
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
+    if (p.dbg && tid == 0) p.dbg[wg * 8ull + 6] = wall_clock64();
+    for (int i = 0; i < nsteps; ++i) {
+        int np = 0;
+        if (p.dbg) dt0 = __builtin_amdgcn_s_memtime();
+        if (i + 2 < nsteps) { const int s2 = slot == 0 ? 2 : slot - 1; FAV_SK_STAGE(s2, np); }
+        if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[0] += dt1 - dt0; dt0 = dt1; }
+        int e_cur = 0;
+        const int tg = tx0 + ctile;
+        const int tm = (int)fastdiv((uint32_t)tg, p.div_tn), tn = tg - tm * p.tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+        if (cfirst) {
+            cfirst = false;
+            if (ck > 0 && !(p.act & 0x100)) {
+                // ---- the tile's head was computed by block wg - 8: wait for it, take its accumulator over -----------------------
+                if (tid == 0) {
+                    const uint32_t* fl = p.flags + (wg - 8);
+                    int spins = 0;
+                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if (++spins > (1 << 22)) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // (descriptor + one per-lane offset: as sixteen 64-bit pointers the slot's addresses were hoisted out of the loop into 64 registers)
+                const __amdgpu_buffer_rsrc_t srd_in = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.ws + (size_t)(wg - 8) * 65536), 0, 65536, 0x00020000);
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(srd_in, tid * 16, (a * TM + b) * 4096, 0);
+                        acc[a][b] = (f32x4_t){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+                    }
+                // the compiler's own wait for these loads goes HERE (an empty statement that redefines the registers): left to itself it
+                // waits in front of the loop's MFMAs - vmcnt(0) in every step, which drains the LDS-DMA ring it does not know about
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) asm volatile("" : "+v"(acc[a][b]));
+            } else {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.res && ckb == p.ksteps) {          // this segment ends in the epilogue: its residual rows, requested a whole tile ahead
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        rr[b][q] = __builtin_amdgcn_raw_buffer_load_b128(
+                            srd_res, (int)((((long long)(m0 + wm * 64 + b * 16 + frow)) * p.N + n0 + wn * 64 + 16 * fq + 8 * q) * 2), 0, 0);
+                e_cur += 2 * TM;
+            }
+        }
+        // ---- one 32-deep step ------------------------------------------------------------------------------------------------
+        {
+            const unsigned char* As = smem + slot * STAGE;
+            const unsigned char* Bs = As + A_BYTES;
+            uint4 fx[TM], fw[TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int row = wm * 64 + b * 16 + frow;
+                fx[b] = *(const uint4*)(As + row * ROWB + ((fq ^ lds_swz<32>(row)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int row = wn * 64 + a * 16 + frow;
+                fw[a] = *(const uint4*)(Bs + row * ROWB + ((fq ^ lds_swz<32>(row)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    union { uint4 u; bf16x8_t v; } ua, ub;
+                    ua.u = fw[a];
+                    ub.u = fx[b];
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[a][b], 0, 0, 0);
+                }
+        }
+        if (p.dbg) { asm volatile("s_nop 0" :: "v"(acc[TN - 1][TM - 1])); dt1 = __builtin_amdgcn_s_memtime(); dsum[1] += dt1 - dt0; dt0 = dt1; }
+        // ---- end of a segment: epilogue, or publish the partial accumulator ----------------------------------------------------
+        if (++ck == ckb) {
+            if (ckb == p.ksteps) {
+                const float* bias_s = (const float*)(smem + NS * STAGE + (cj & 3) * 1024);
+                float bia[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bq = *(const float4*)(bias_s + wn * 64 + 16 * fq + 4 * q);
+                    bia[4 * q] = bq.x; bia[4 * q + 1] = bq.y; bia[4 * q + 2] = bq.z; bia[4 * q + 3] = bq.w;
+                }
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = m0 + wm * 64 + b * 16 + frow;
+#pragma unroll
+                    for (int h8 = 0; h8 < 2; ++h8) {
+                        __builtin_amdgcn_sched_barrier(0);       // one 8-channel group at a time: the GELU's temporaries are not worth a fourth of the register file
+                        float v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc[2 * h8 + (k >> 2)][b][k & 3], bia[8 * h8 + k]);
+                        if (p.res) {
+                            const uint32_t rw[4] = {rr[b][h8][0], rr[b][h8][1], rr[b][h8][2], rr[b][h8][3]};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                v[2 * k] = __fadd_rn(v[2 * k], bf16_bits_to_f32(rw[k] & 0xFFFFu));
+                                v[2 * k + 1] = __fadd_rn(v[2 * k + 1], bf16_bits_to_f32(rw[k] >> 16));
+                            }
+                        }
+                        if ((p.act & 0xff) == 1) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                        } else if ((p.act & 0xff) == 2) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = fav_gelu(v[k]);
+                        }
+                        const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        // rows beyond M fail the descriptor's range check
+                        __builtin_amdgcn_raw_buffer_store_b128(o, srd_y, m < p.M ? (int)(((long long)m * p.N + n0 + wn * 64 + 16 * fq + 8 * h8) * 2) : (int)OOB, 0, 0);
+                    }
+                }
+                e_cur += 2 * TM;
+            } else if (!(p.act & 0x100)) {
+                const __amdgpu_buffer_rsrc_t srd_out = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.ws + (size_t)wg * 65536), 0, 65536, 0x00020000);
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const u32x4_t v = {__float_as_uint(acc[a][b][0]), __float_as_uint(acc[a][b][1]), __float_as_uint(acc[a][b][2]), __float_as_uint(acc[a][b][3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, srd_out, tid * 16, (a * TM + b) * 4096, 0);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's part of the slot has left
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.flags + wg, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (++cj < nseg) { FAV_SK_SEG(cj, ctile, ck, ckb); cfirst = true; }
+        }
+        // ---- step i + 1 has landed: everything issued behind its stage may stay in flight ----------------------------------------
+        if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[2] += dt1 - dt0; dt0 = dt1; }
+        if (i + 1 < nsteps) {
+            sk_wait_vmcnt(e_prev + np + e_cur);
+            if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[3] += dt1 - dt0; dt0 = dt1; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[4] += dt1 - dt0; dt0 = dt1; }
+        }
+        e_prev = e_cur;
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (p.dbg && tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p.dbg[wg * 8ull + k] = dsum[k];
+        p.dbg[wg * 8ull + 5] = (unsigned long long)nsteps;
+        p.dbg[wg * 8ull + 7] = wall_clock64();
+    }
+#undef FAV_SK_STAGE
+#undef FAV_SK_PTILE
+#undef FAV_SK_SEG
 }
 
 // ---------------------------------------------------------------------------

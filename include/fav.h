@@ -241,6 +241,17 @@ fav_status fav_op_layernorm(const void* x, int64_t ldx, const float* gamma, cons
  * softmax(Q K^T / 8) V per head, T <= 256, D = 64 * heads. */
 fav_status fav_op_attention(const void* qkv, void* out, int32_t n, int32_t T, int32_t D, int32_t heads,
                             int32_t math_mode, void* hip_stream);
+/* One linear layer of the encoder as the chained stream-K GEMM (gemm_streamk_kernel): y[rows][N] = act((x[rows][K] w[N][K]^T + bias) + res),
+ * bf16 in and out, fp32 bias; res may be NULL or y itself (in-place residual); act 0 none, 1 ReLU, 2 tanh-form GELU.  Bit-identical to
+ * fav_op_conv2d with kh = kw = 1 on the same operands (the K steps are dealt out evenly over a persistent grid and a tile's partial
+ * accumulator is handed on, never re-associated).  K % 32 == 0, N % 128 == 0, at least 256 tiles of 128 x 128; production math only.
+ * No reference counterpart (the slot is platform/backend/main.py:160). */
+typedef struct fav_linear_desc {
+    const void* x; const void* w; const float* bias; const void* res; void* y;
+    int64_t rows;
+    int32_t K, N, act;
+} fav_linear_desc;
+fav_status fav_op_linear_streamk(const fav_linear_desc* d, void* hip_stream);
 /* Token assembly: x[f][0] = pos[0], x[f][1 + p] = bf16(emb[f][p] + pos[1 + p]); emb [n][ntok-1][D] bf16, pos fp32. */
 fav_status fav_op_vit_assemble(const void* emb, const float* pos, void* x, int32_t n, int32_t ntok, int32_t D,
                                void* hip_stream);
