@@ -33,6 +33,7 @@ class FavConfig(C.Structure):
         ("n_samples", C.c_int32), ("site_mask", C.c_uint32), ("dropout_p", C.c_float), ("seed", C.c_uint64),
         ("temperature", C.c_float), ("conf_kind", C.c_int32), ("tau", C.c_float), ("math_mode", C.c_int32),
         ("chunk_a", C.c_int32), ("chunk_b", C.c_int32), ("regroup_block", C.c_int32), ("n_members", C.c_int32),
+        ("tail_min_rows", C.c_int32), ("ens_grouped_max", C.c_int32), ("vit_streams", C.c_int32), ("stem_fused", C.c_int32),
     ]
 
 

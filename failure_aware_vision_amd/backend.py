@@ -36,7 +36,8 @@ class Backend:
                  n_samples: int = 1, dropout_policy: str = "none", dropout_p: float = 0.0, seed: int = 0,
                  site_mask: int | None = None, temperature: float = 1.0, conf_kind: str = "max_softmax",
                  tau: float = 0.5, math_mode: str = "bf16", mean=None, std=None,
-                 chunk_a: int = 0, chunk_b: int = 0, regroup_block: int = -1):
+                 chunk_a: int = 0, chunk_b: int = 0, regroup_block: int = -1,
+                 tail_min_rows: int = 0, ens_grouped_max: int = 0, vit_streams: int = 0, stem_fused: int = 0):
         import torch
         self._torch = torch
         self._h = None
@@ -68,6 +69,9 @@ class Backend:
         cfg.tau = float(tau)
         cfg.math_mode = _MATH[math_mode]
         cfg.chunk_a, cfg.chunk_b, cfg.regroup_block = int(chunk_a), int(chunk_b), int(regroup_block)
+        # schedule choices (fav_config, ABI 2): 0 = the build's measured default; results never depend on them
+        cfg.tail_min_rows, cfg.ens_grouped_max = int(tail_min_rows), int(ens_grouped_max)
+        cfg.vit_streams, cfg.stem_fused = int(vit_streams), int(stem_fused)
         members = list(blob) if isinstance(blob, (list, tuple)) else None   # deep ensemble: one blob per member
         cfg.n_members = len(members) if members else 1
         self.cfg = cfg
@@ -239,9 +243,11 @@ class Backend:
         ref_metrics = {"blur": 0.0, "brightness": 0.0, "freeze": 0.0, "entropy": 0.0, "raw": {}}
         rule_score = None
         rules, saved = None, None
+        # the caller's callback runs OUTSIDE the guarded region: an exception in it is the caller's bug and propagates; only the
+        # device path below fails closed
+        status = status_provider(frame) if status_provider is not None else None
         try:
             if status_provider is not None:
-                status = status_provider(frame)
                 labels, conf, fail, score = self.classify_detect(fr[None])
                 l0, c0, f0, s0 = int(labels[0]), float(conf[0]), bool(fail[0]), float(score[0])
             else:

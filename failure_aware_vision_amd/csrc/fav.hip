@@ -143,7 +143,7 @@ struct fav_handle {
                       hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     std::vector<MemberWs> mws;
     hipEvent_t ev_members = nullptr;
-    // Grouped launches (FAV_ENS_GROUPED, default: calls of up to FAV_ENS_GROUPED_MAX frames, see classify_on_stream): every op of
+    // Grouped launches (default: every call; fav_config.ens_grouped_max limits the frames per call or switches them off): every op of
     // the schedule is ONE launch over all members - block row blockIdx.y is member y, whose tensors lie at a constant byte
     // stride behind member 0's (the workspaces and the weights are slabs).  `grp` is what the launchers add to a launch.
     struct Group { int n = 1; long long x = 0, w = 0, b = 0, res = 0, y = 0, wb = 0, bb = 0, wa = 0, ba = 0, y2 = 0; };
@@ -187,6 +187,19 @@ struct fav_handle {
 namespace {
 
 using namespace fav;
+
+// Experiment knobs.  A normal build has NONE: every FAV_KNOB below is its measured default, a compile-time constant, and the
+// library reads no environment variable.  `make EXPERIMENTS=1` (-DFAV_EXPERIMENTS) turns them back into environment variables -
+// that build is what tools/*_bench.py, the phase-clock dumps and the A/B records under profiles/ use.  Decided schedule choices
+// a caller may want to override are fav_config fields (tail_min_rows, ens_grouped_max, vit_streams, stem_fused), not knobs.
+#ifdef FAV_EXPERIMENTS
+long long fav_knob_read(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
+#define FAV_KNOB(NAME, DFLT) ([] { static const long long v_ = fav_knob_read(NAME, (DFLT)); return v_; }())
+const char* fav_knob_str(const char* name) { return getenv(name); }
+#else
+#define FAV_KNOB(NAME, DFLT) ((long long)(DFLT))
+const char* fav_knob_str(const char*) { return nullptr; }
+#endif
 
 int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
 
@@ -254,25 +267,15 @@ DropParams make_drop(const fav_dropout_desc* d) {
 //    epilogue; 32-deep tiles with a 3-stage ring (50 KB of LDS -> 3 blocks per CU, which is also
 //    what the 143 VGPRs allow);
 //  * 1x1 without residual: the same up to K = 256; 64-deep tiles and a double buffer from K = 512.
-// FAV_CONV_BK=32|64 and FAV_CONV_NS=2|3|4 force a value for experiments.
+// FAV_CONV_BK=32|64 forces a value (experiments build).
 int conv_bk(int kh, int kw, int K, bool has_res) {
-    static int forced = [] { const char* e = getenv("FAV_CONV_BK"); return e ? atoi(e) : 0; }();
+    const int forced = (int)FAV_KNOB("FAV_CONV_BK", 0);
     if (forced == 32 || forced == 64) return forced;
     return (kh * kw > 1 || (!has_res && K >= 512) || K >= 1024) ? 64 : 32;   // K >= 1024 with a residual: the ViT MLP's second GEMM
 }
 
 // ring depth: three 32-deep stages or two 64-deep ones (the other depths measured no better; their
 // instantiations were dropped in round 3) - fixed in the launch table of launch_conv
-
-// M-tile height: 256-row tiles (8 waves, 96 KB of LDS, one block per CU) raise the
-// FLOPs per byte staged from L2 for the MFMA-bound 3x3 convolutions; everything else
-// uses 128 rows.  256-row tiles always use 64-deep K tiles.  FAV_CONV_BM=128|256 forces.
-int conv_bm(int kh, int kw, long long M) {
-    static int forced = [] { const char* e = getenv("FAV_CONV_BM"); return e ? atoi(e) : 0; }();
-    (void)forced;
-    (void)kh; (void)kw; (void)M;
-    return 128;  // measured: 256-row tiles (1 block/CU) lose to 2 blocks/CU of 128-row tiles on every 3x3 shape
-}
 
 // 256 x 256 x 64 tile (8 waves, 128 KB of LDS, one block per CU): twice the FLOPs per
 // byte staged from L2, which is what bounds the MFMA-heavy shapes.
@@ -281,8 +284,8 @@ int conv_bm(int kh, int kw, long long M) {
 // time is the epilogue (nothing overlaps it at one block per CU).  FAV_CONV_BIG: 0 never, 1 always
 // when Cout % 256 == 0, unset = the measured rule.
 bool conv_big(int kh, int kw, long long M, int cout_pad, int K, bool has_res) {
-    static int mode = [] { const char* e = getenv("FAV_CONV_BIG"); return e ? atoi(e) : 2; }();
-    static long long min_m = [] { const char* e = getenv("FAV_CONV_BIG_MINM"); return e ? atoll(e) : 8192ll; }();
+    const int mode = (int)FAV_KNOB("FAV_CONV_BIG", 2);
+    const long long min_m = FAV_KNOB("FAV_CONV_BIG_MINM", 8192);
     if (mode == 0 || cout_pad % 256 != 0 || M < min_m) return false;
     if (mode == 1) return true;
     if ((M / 256) * (cout_pad / 256) < 512) return false;   // fewer than two 256x256 tiles per CU: 128-row tiles fill the chip better
@@ -294,8 +297,7 @@ bool conv_big(int kh, int kw, long long M, int cout_pad, int K, bool has_res) {
 //      costs nothing there), the 512 output channels stream through as 8 weight chunks, register epilogue.  Measured
 //      against the generic kernel on layer 2's shortcut (56x56x256 -> 28x28x512): see profiles/r2e_*.  FAV_PROJ=0 disables.
 bool proj_enabled() {
-    static const int on = [] { const char* e = getenv("FAV_PROJ"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return FAV_KNOB("FAV_PROJ", 1) != 0;
 }
 
 bool launch_proj(fav_handle* h, const fav_conv_desc& d, hipStream_t s) {
@@ -373,12 +375,12 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     // epilogue has nothing to hide behind at one block per CU) and the 64-deep steps (594 tiles do not fill 2 x 256 slots twice)
     const bool vit = h && h->vit;
     // ViT: the 256 x 256 tile only for launches with >= FAV_VIT_BIG_TILES of them (default: never at the per-GPU share of 64 frames, see below)
-    static const long long vit_big_tiles = [] { const char* e = getenv("FAV_VIT_BIG_TILES"); return e ? atoll(e) : 512ll; }();
+    const long long vit_big_tiles = FAV_KNOB("FAV_VIT_BIG_TILES", 512);
     const bool vit_big = vit && (M / 256) * (cout_pad / 256) >= vit_big_tiles;
     const bool big = (!vit || vit_big) && conv_big(d.kh, d.kw, M * G.n, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
     const int BK = big ? 64 : (vit ? 32 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr));
-    const int BM = big ? 256 : conv_bm(d.kh, d.kw, M);
+    const int BM = big ? 256 : 128;   // (256-row tiles with 128 columns lose to two blocks per CU of 128-row tiles on every 3x3 shape)
     // measured: issuing the DMA after the first MFMA group gains ~7 % on the 256x256 3x3 launches and
     // loses 3-5 % on the 128-row tiles and on every 1x1
     p.stage_mid = (big && d.kh * d.kw > 1) ? 1 : 0;
@@ -395,7 +397,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const double flops = 2.0 * (double)M * d.Cout * p.K * G.n;
     const double bytes = 2.0 * ((double)d.n_frames * d.H * d.W * d.Cin + (double)M * d.Cout * (d.res ? 2 : 1) * (d.out_f32 ? 2 : 1)
                                 + (double)d.Cout * p.K) * G.n;
-    static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
+    const bool dbg_on = FAV_KNOB("FAV_CONV_DBG", 0) != 0;   // experiments build only: per-block phase clocks
     if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)tiles * 32); (void)hipMemset(p.dbg, 0, (size_t)tiles * 32); }
     auto dbg_report = [&](long long nblocks, int bm, int bn, int bk) {
         if (!p.dbg) return;
@@ -417,13 +419,13 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
     // 3x3 / stride 1 / pad 1 with Cin <= 128 and the whole Cout in one tile: the input patch is staged once
     // per 256 output pixels instead of once per tap (conv3x3_halo_kernel).  FAV_CONV_HALO=0 disables.
-    static const int halo_mode = [] { const char* e = getenv("FAV_CONV_HALO"); return e ? atoi(e) : 1; }();
+    const int halo_mode = (int)FAV_KNOB("FAV_CONV_HALO", 1);
     if (halo_mode && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 && !d.res && p.drop.site < 0 && !d.out_f32 &&
         (d.Cin == 64 || d.Cin == 128) && d.Cout == cout_pad && d.Cout == d.Cin && M * G.n >= 2048) {
         // Cin 64: 512-pixel tiles, all 9 K tiles of the weights resident; Cin 128: 256-pixel tiles, weights double-buffered per tap
         // 256-pixel tiles, 8 waves (measured best on both shapes); FAV_HALO_CFG=0 selects 128-pixel tiles with 4 waves and
         // several blocks per CU for experiments
-        static const int halo_cfg = [] { const char* e = getenv("FAV_HALO_CFG"); return e ? atoi(e) : 1; }();
+        const int halo_cfg = (int)FAV_KNOB("FAV_HALO_CFG", 1);
         const int HBM = halo_cfg == 0 ? 128 : 256;
         const int wstages = d.Cin == 64 ? (halo_cfg == 0 ? 2 : 3) : (halo_cfg == 0 ? 2 : 4);   // K tiles of weights held in LDS
         const int patch_bytes = (int)((((long long)(HBM + 2 * d.W + 2) * d.Cin * 2) + 1023) / 1024 * 1024);
@@ -462,7 +464,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     // measured (profiles/r2b_conv_epilogue_ab.txt): the register epilogue wins 2-4 % on the 3x3 and K >= 512 launches
     // (also with a residual on the 256 x 256 tile: layer 4's expand 1.24 vs 1.29 ms) and loses ~3 % on the 128-row
     // tiles with a residual, so those keep the staged one.  FAV_CONV_EPI=0|1 forces.
-    static const int epi_forced = [] { const char* e = getenv("FAV_CONV_EPI"); return e ? atoi(e) : -1; }();
+    const int epi_forced = (int)FAV_KNOB("FAV_CONV_EPI", -1);
     const int epi = epi_forced >= 0 ? epi_forced : ((d.res && !big) ? 0 : 1);
 #define FAV_LAUNCH(BN_, BK_, NS_, MODE_)                                                                          \
     do {                                                                                                          \
@@ -476,7 +478,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     } while (0)
 #define FAV_LAUNCH_BIG(MODE_)                                                                                     \
     do {                                                                                                          \
-        static const int pp = [] { const char* e = getenv("FAV_CONV_PP"); return e ? atoi(e) : 1; }();           \
+        const int pp = (int)FAV_KNOB("FAV_CONV_PP", 1);                                                           \
         if (epi && pp && MODE_ == 0) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0, 2, 0, 1, 1>), grid, dim3(512), 0, s, p); \
         else if (epi) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 1>), grid, dim3(512), 0, s, p);    \
         else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 0>), grid, dim3(512), 0, s, p);        \
@@ -496,8 +498,7 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 struct TailGeom { int patch_bytes, rega_bytes, lds_bytes, nw, wc2, rp, bias_b_off, bias_ca_off, wa_off0, wa_off1, zero_off; };
 // 512 mid channels (layer 4): the expanding 1x1 + residual + dropout on the row-owning structure.  FAV_TAIL_L4=0 disables.
 bool tail_l4() {
-    static const int on = [] { const char* e = getenv("FAV_TAIL_L4"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return FAV_KNOB("FAV_TAIL_L4", 1) != 0;
 }
 // LDS plan of bottleneck_tail_kernel<CMID, NRED, HAS3X3, NS, NW, WC2> (must match the kernel's own layout)
 bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
@@ -557,27 +558,17 @@ bool tail_geometry(int cmid, int nred, bool has3x3, int W, TailGeom* g) {
 }
 
 bool tail_wide() {
-    static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
-
-// 256 mid channels + the next block's reduce in one launch (8 waves x 16 rows, one weight fragment read per MFMA):
-// measured 3.01 ms against 1.77 ms (expand alone as a tail) + 0.95 ms (generic reduce) -> off by default
-bool tail_wide_reduce() {
-    static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE_REDUCE"); return e ? atoi(e) : 0; }();
-    return on != 0;
+    return FAV_KNOB("FAV_TAIL_WIDE", 1) != 0;
 }
 
 // 256 mid channels: conv_b (generic loop) + conv_c in one launch.  FAV_TAIL_WIDE3X3=0 keeps the 3x3 as its own launch.
 bool tail_wide3x3() {
-    static const int on = [] { const char* e = getenv("FAV_TAIL_WIDE3X3"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return FAV_KNOB("FAV_TAIL_WIDE3X3", 1) != 0;
 }
 
 // 512 mid channels (layer 4): the expanding 1x1 + residual + dropout on the row-owning structure.  FAV_TAIL_L4=0 disables.
 bool tail_enabled() {
-    static const int on = [] { const char* e = getenv("FAV_FUSE"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return FAV_KNOB("FAV_FUSE", 1) != 0;
 }
 
 const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
@@ -615,12 +606,12 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
     const double res_rows = d.res_entry ? (double)std::min<long long>(d.n_frames, p.drop.n_img) * p.HW : (double)M;
     const double bytes = 2.0 * ((double)M * (cmid + 1.0 * cout + nred) + res_rows * cout + (has3x3 ? 9.0 * cmid * cmid : 0.0) + (double)cmid * cout + (double)cout * nred) * G.n;
     Prof pr(h, s, FAV_K_CONV, flops, bytes);
-    { static const int lds_pad = [] { const char* e = getenv("FAV_TAIL_LDS_PAD"); return e ? atoi(e) : 0; }(); if (g.lds_bytes + lds_pad <= 160 * 1024) g.lds_bytes += lds_pad; }   // experiments: fewer blocks per CU
+    { const int lds_pad = (int)FAV_KNOB("FAV_TAIL_LDS_PAD", 0); if (g.lds_bytes + lds_pad <= 160 * 1024) g.lds_bytes += lds_pad; }   // experiments build: fewer blocks per CU
     const int bm = g.rp * g.nw;
     const long long nblocks = (M + bm - 1) / bm;
     dim3 grid((unsigned)nblocks, G.n);
     p.dbg = nullptr;
-    static const bool dbg_on = getenv("FAV_CONV_DBG") != nullptr;   // experiments only: per-block phase clocks
+    const bool dbg_on = FAV_KNOB("FAV_CONV_DBG", 0) != 0;   // experiments build only: per-block phase clocks
     if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)nblocks * 128); (void)hipMemset(p.dbg, 0, (size_t)nblocks * 128); }
     auto dbg_report = [&]() {
         if (!p.dbg) return;
@@ -628,7 +619,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
         std::vector<unsigned long long> t((size_t)nblocks * 16);
         (void)hipMemcpy(t.data(), p.dbg, t.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(p.dbg);
-        if (const char* dump = getenv("FAV_CONV_DBG_DUMP")) {     // raw stamps, [block][16] u64, appended: tools/phase_overlap.py
+        if (const char* dump = fav_knob_str("FAV_CONV_DBG_DUMP")) {     // raw stamps, [block][16] u64, appended: tools/phase_overlap.py
             if (FILE* f = fopen(dump, "ab")) { const long long hdr[2] = {nblocks, cmid * 1000 + nred}; fwrite(hdr, 8, 2, f); fwrite(t.data(), 8, t.size(), f); fclose(f); }
         }
         unsigned long long lo = ~0ull, hi = 0;
@@ -668,7 +659,7 @@ const char* launch_tail(fav_handle* h, const fav_tail_desc& d, hipStream_t s) {
 #define FAV_TAIL_N(CMID_, NRED_, H3_, NS_) FAV_TAIL_W(CMID_, NRED_, H3_, NS_, 4)
     if (d.res_entry) {
         // whole samples, tiles that do not straddle them: the T tiles over one pixel tile of the cached tensor run back to back
-        static const bool sample_minor = [] { const char* e = getenv("FAV_ENTRY_RES_ORDER"); return !e || atoi(e) != 0; }();
+        const bool sample_minor = FAV_KNOB("FAV_ENTRY_RES_ORDER", 1) != 0;
         const long long sample_rows = (long long)p.drop.n_img * p.HW;
         if (sample_minor && p.drop.v0 % p.drop.n_img == 0 && d.n_frames % p.drop.n_img == 0 && sample_rows % bm == 0) {
             p.rs_T = d.n_frames / p.drop.n_img;
@@ -760,12 +751,6 @@ void launch_maxpool(fav_handle* h, const void* x, void* y, int n, int H, int W, 
                        C, Ho, Wo);
 }
 
-// FAV_STEM_FUSED=0: the ImageNet stem as three launches (im2col rows, GEMM, max pool) instead of stem7_pool_kernel
-bool stem_fused_enabled() {
-    static const bool on = [] { const char* e = getenv("FAV_STEM_FUSED"); return !e || atoi(e) != 0; }();
-    return on;
-}
-
 // normalise + 7x7/2 conv (64 channels, weights [64][192]) + bias + ReLU + 3x3/2 max pool, frames -> [n][Hp][Wp][64] bf16
 const char* launch_stem_pool(fav_handle* h, const void* images, int layout, int n, int H, int W, const void* w, const float* bias,
                              const float* mean, const float* istd, void* out, hipStream_t s) {
@@ -813,8 +798,7 @@ void launch_entry_dropout(fav_handle* h, const void* x, void* out, long long ele
 // Entry dropout + the 1x1 reduce behind it (entry_reduce_kernel): 256 -> 64 channels, the first dropout site of the
 // all_blocks policy.  FAV_ENTRY_FUSE=0 keeps the two launches.
 bool entry_reduce_enabled() {
-    static const int on = [] { const char* e = getenv("FAV_ENTRY_FUSE"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return FAV_KNOB("FAV_ENTRY_FUSE", 1) != 0;
 }
 bool entry_reduce_supported(int C, int nred, long long n_img, long long HW) {
     return C == 256 && nred == 64 && n_img * HW * C * 2 < 0x70000000LL;     // 32-bit byte offsets into the cached tensor
@@ -883,8 +867,7 @@ bool sk_prepare(fav_handle::SkWs* w, int grid) {
 // the hand-offs' agent-scope fences and 2 x 64 KB per workgroup cost ~25 % of a launch, and shares that start at different K steps
 // lose the lock step that keeps the tile kernel's LDS-DMA stream in the XCD's 4 MB L2).  FAV_STREAMK=1 routes the encoder through it.
 bool streamk_enabled() {
-    static const int on = [] { const char* e = getenv("FAV_STREAMK"); return e ? atoi(e) : 0; }();
-    return on != 0;
+    return FAV_KNOB("FAV_STREAMK", 0) != 0;
 }
 bool launch_gemm_streamk(fav_handle* h, const void* a, const void* w, const float* bias, const void* res, void* y, long long M, int K, int N,
                          int act, hipStream_t s) {
@@ -910,7 +893,7 @@ bool launch_gemm_streamk(fav_handle* h, const void* a, const void* w, const floa
     p.M = (int)M; p.N = N; p.K = K; p.ksteps = K / 32;
     p.tiles_n = N / 128; p.tiles = (int)tiles;
     p.act = act;
-    { static const bool nohand = getenv("FAV_SK_NOHANDOFF") != nullptr; if (nohand) p.act |= 0x100; }   // TIMING ONLY (wrong results): what the hand-offs cost
+    if (FAV_KNOB("FAV_SK_NOHANDOFF", 0) != 0) p.act |= 0x100;   // experiments build, TIMING ONLY (wrong results): what the hand-offs cost
     p.Q = grid / 8;
     p.ws = W->ws; p.flags = W->flags; p.err = W->err;
     p.epoch = ++W->epoch;
@@ -927,7 +910,7 @@ bool launch_gemm_streamk(fav_handle* h, const void* a, const void* w, const floa
         if (hipFuncSetAttribute((const void*)gemm_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
         attr_set.set_current();
     }
-    static const bool dbg_on = getenv("FAV_SK_DBG") != nullptr;   // experiments only: where a step's ticks go
+    const bool dbg_on = FAV_KNOB("FAV_SK_DBG", 0) != 0;   // experiments build only: where a step's ticks go
     if (dbg_on && !h) { (void)hipMalloc((void**)&p.dbg, (size_t)grid * 64); (void)hipMemset(p.dbg, 0, (size_t)grid * 64); }
     hipLaunchKernelGGL(gemm_streamk_kernel, dim3((unsigned)grid), dim3(256), pad_lds, s, p);
     if (p.dbg) {
@@ -955,7 +938,7 @@ const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, i
     // one wave per query tile if their P strips fit beside K and V (197 tokens: 13 waves, 152 KB), else 8 waves round robin
     int nw = nkt > 8 ? nkt : 8;
     if (nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride > 160 * 1024) nw = 8;
-    static const int attn_nw = [] { const char* e = getenv("FAV_ATTN_WAVES"); return e ? atoi(e) : 0; }();   // experiments: 8 forces the old shape
+    const int attn_nw = (int)FAV_KNOB("FAV_ATTN_WAVES", 0);   // experiments build: 8 forces the old shape
     if (attn_nw == 8) nw = 8;
     const int lds = nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride;
     static DeviceFlags attr_set;
@@ -981,6 +964,17 @@ void launch_vit_assemble(fav_handle* h, const void* emb, const float* pos, void*
     const long long total = (long long)n * ntok * (D / 4);
     Prof pr(h, s, FAV_K_STEM, 0.0, (double)n * ntok * D * 4);
     hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)emb, pos, (uint16_t*)x, n, ntok, D);
+}
+
+// A deep ensemble runs every op as ONE launch over its members (classify_on_stream) when: there is no MC-Dropout suffix, the
+// production math mode, the one-launch stem, the members' workspaces side by side, fav_config.ens_grouped_max >= 0 - and the call
+// has at most ens_grouped_max frames.  build_graph plans the size-dependent tail kernels of layers 3-4 for max_batch frames, so it
+// asks with the same predicate whether a call of max_batch frames will be grouped.
+bool will_group(const fav_handle* h, bool has_mc, bool stem_fused) {
+    const fav_config& c = h->cfg;
+    if (h->n_members <= 1 || has_mc || c.math_mode != FAV_MATH_BF16 || !stem_fused || c.ens_grouped_max < 0) return false;
+    if (FAV_KNOB("FAV_ENS_STREAMS", 1) == 0) return false;
+    return c.ens_grouped_max == 0 || c.max_batch <= c.ens_grouped_max;
 }
 
 fav_status build_graph(fav_handle* h) {
@@ -1016,7 +1010,7 @@ fav_status build_graph(fav_handle* h) {
         return -1;
     };
     // production math mode: the whole ImageNet stem (normalise, 7x7/2, ReLU, max pool) is one launch
-    const bool stem_fused = A.imagenet_stem && c.math_mode == FAV_MATH_BF16 && stem_fused_enabled() && !h->plan_no_fuse &&
+    const bool stem_fused = A.imagenet_stem && c.math_mode == FAV_MATH_BF16 && c.stem_fused >= 0 && !h->plan_no_fuse &&
                             conv_out(Ho, 3, 2, 1) >= 1 && conv_out(Wo, 3, 2, 1) >= 1;
     int stem_ops = 0;
     if (stem_fused) {
@@ -1097,13 +1091,11 @@ fav_status build_graph(fav_handle* h) {
                 // the 256-pixel / 8-wave kernels of layers 3-4 run one block per CU: they pay only when the planned launch
                 // (max_batch frames, x T samples behind the first dropout site) brings two blocks per CU
                 // (an ensemble without MC-Dropout runs every op as one launch over its members, see classify_on_stream)
-                const char* grp_env = getenv("FAV_ENS_GROUPED");
-                const int plan_groups = (h->n_members > 1 && mc_first_site < 0 && !(grp_env && atoi(grp_env) == 0)) ? h->n_members : 1;
+                const int plan_groups = will_group(h, mc_first_site >= 0, stem_fused) ? h->n_members : 1;
                 const long long plan_rows = (long long)c.max_batch * ((mc_first_site >= 0 && bidx > mc_first_site) ? c.n_samples : 1) * Hn * Wn * plan_groups;
-                const char* min_rows_env = getenv("FAV_TAIL_MIN_ROWS");        // tests: 0 forces those kernels at any size
-                const bool big_launch = plan_rows >= (min_rows_env ? atoll(min_rows_env) : 512ll * 256);
+                const bool big_launch = c.tail_min_rows < 0 || plan_rows >= (c.tail_min_rows > 0 ? (long long)c.tail_min_rows : 512ll * 256);
                 const bool tail_3x3 = (s == 1) && (pl <= 128 || (pl == 256 && tail_wide3x3() && big_launch));
-                if (pl > 128 && (nred != pl || !tail_wide_reduce())) nred = 0;   // wide blocks: the expanding 1x1 (+ the next reduce inside a stage)
+                if (pl > 128) nred = 0;   // wide blocks: the expanding 1x1 alone (with the next block's reduce in the launch it measured 3.01 ms against 1.77 + 0.95: only fav_op_bottleneck_tail still reaches that kernel)
                 bool fuse = tail_enabled() && !h->plan_no_fuse && c.math_mode == FAV_MATH_BF16 && (pl == 64 || pl == 128 || (pl == 256 && tail_wide()) || (pl == 512 && tail_l4() && big_launch));
                 if (fuse && !tail_geometry(pl, nred, tail_3x3, Wn, &tg)) {
                     nred = 0;
@@ -1234,7 +1226,7 @@ fav_status build_graph(fav_handle* h) {
                     // The block behind the entry: its tail can take its residual - the dropped copy of the cached prefix output -
                     // from the cached tensor itself and apply the entry mask in its epilogue; the T copies are then neither
                     // written (12 GB per step at the headline shape) nor read back.  FAV_ENTRY_RES=0 keeps them.
-                    static const bool entry_res = [] { const char* e = getenv("FAV_ENTRY_RES"); return !e || atoi(e) != 0; }();
+                    const bool entry_res = FAV_KNOB("FAV_ENTRY_RES", 1) != 0;
                     const int y0 = f.out;
                     if (entry_res && split + 1 < (int)h->ops.size() && regroup_now != split + 1) {
                         Op& tl = h->ops[split + 1];
@@ -1314,7 +1306,7 @@ fav_status plan_memory(fav_handle* h) {
     // measured on MI355X the two kernels only time-share the CUs (each already fills every
     // CU's LDS), 118.5 ms/step off vs 119.0-121.2 with 2..16 chunks.
     {
-        static int npipe = [] { const char* e = getenv("FAV_PIPE"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+        const int npipe = (int)std::max<long long>(1, FAV_KNOB("FAV_PIPE", 1));
         const size_t np = h->phases.size();
         h->pipe_first = -1;
         if (npipe > 1 && np >= 2 && h->phases[np - 1].suffix == h->phases[np - 2].suffix) {
@@ -1346,7 +1338,7 @@ fav_status plan_memory(fav_handle* h) {
     a1_bytes = (a1_bytes + 255) / 256 * 256 + 256;
     // deep ensemble with its members side by side: every workspace tensor is a slab of n_members equal parts (member 0's part
     // is the handle's own buffer), so that a grouped launch finds member g's tensors at a constant stride
-    static const int ens_streams = [] { const char* e = getenv("FAV_ENS_STREAMS"); return e ? atoi(e) : 1; }();
+    const int ens_streams = (int)FAV_KNOB("FAV_ENS_STREAMS", 1);
     const bool side_by_side = h->n_members > 1 && ens_streams && h->pipe_first < 0;
     const size_t parts = side_by_side ? (size_t)h->n_members : 1;
     for (int i = 0; i < 5; ++i) HIP_TRY(h, hipMalloc(&h->act[i], act_bytes * parts));
@@ -1390,8 +1382,8 @@ fav_status plan_memory(fav_handle* h) {
         for (const Op& o : h->ops)
             if (o.kind != OP_STEM_POOL && o.kind != OP_CONV && o.kind != OP_TAIL && o.kind != OP_AVGPOOL) h->can_group = false;
         for (const Op& o : h->ops) if (o.site >= 0) h->can_group = false;
-        const char* ge = getenv("FAV_ENS_GROUPED");           // 0: never; N > 0: only calls of up to N frames (default: every call)
-        h->group_max_frames = ge ? atoi(ge) : 0x7fffffff;
+        if (c.ens_grouped_max < 0) h->can_group = false;      // (build_graph planned with will_group(): the same conditions, asked for max_batch frames)
+        h->group_max_frames = c.ens_grouped_max > 0 ? c.ens_grouped_max : 0x7fffffff;
     }
     return FAV_OK;
 }
@@ -1709,6 +1701,7 @@ fav_status fav_create(const fav_config* cfg, fav_handle** out) {
         cfg->n_samples < 1 || cfg->n_samples > 4096 || !(cfg->temperature > 0.f) || cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f ||
         !(cfg->stdev[0] > 0.f && cfg->stdev[1] > 0.f && cfg->stdev[2] > 0.f) || cfg->math_mode < 0 || cfg->math_mode > 1 ||
         cfg->conf_kind < 0 || cfg->conf_kind > 1 || cfg->n_members < 0 || cfg->n_members > 64 ||
+        cfg->tail_min_rows < -1 || cfg->ens_grouped_max < -1 || cfg->vit_streams < 0 || cfg->vit_streams > 4 || cfg->stem_fused < -1 || cfg->stem_fused > 0 ||
         (cfg->n_members > 1 && cfg->site_mask != 0 && cfg->dropout_p > 0.f)) {   // ensemble members are deterministic
         g_create_error = "fav_create: config value out of range";
         return FAV_ERR_INVALID_ARG;
@@ -1801,14 +1794,19 @@ fav_status fav_check_blob(const void* blob, size_t size, char* err, size_t err_c
         memcpy(off, p + 32 + 48 * i + 32, 16);
         const uint64_t cout = t[0], cin = t[1], kh = t[2], kw = t[3];
         if (cout == 0 || cout > (1u << 24) || cin > (1u << 20) || kh > 64 || kw > 64) return fail(fmt("layer %zu: implausible shape", i));
+        // every value must be finite: a NaN weight would defeat the pixel sanitiser and the bf16 rounding recipe (exponent all ones = Inf / NaN)
+        auto f32_finite = [&](uint64_t o, uint64_t n) { for (uint64_t j = 0; j < n; ++j) { uint32_t u; memcpy(&u, p + o + 4 * j, 4); if ((u & 0x7F800000u) == 0x7F800000u) return false; } return true; };
+        auto bf16_finite = [&](uint64_t o, uint64_t n) { for (uint64_t j = 0; j < n; ++j) { uint16_t u; memcpy(&u, p + o + 2 * j, 2); if ((u & 0x7F80u) == 0x7F80u) return false; } return true; };
         if (kh == 0) {   // a pair of fp32 vectors
             if (!in_range(off[0], cout * 4, 4) || !in_range(off[1], cout * 4, 4)) return fail(fmt("layer %zu data out of range", i));
+            if (!f32_finite(off[0], cout) || !f32_finite(off[1], cout)) return fail(fmt("layer %zu holds a non-finite value", i));
             continue;
         }
         if (kw == 0 || cin == 0) return fail(fmt("layer %zu: implausible shape", i));
         const uint64_t k = kh * kw * cin;   // < 2^32
         if (k > (1ull << 32) / cout) return fail(fmt("layer %zu: implausible shape", i));
         if (!in_range(off[0], cout * k * 2, 2) || !in_range(off[1], cout * 4, 4)) return fail(fmt("layer %zu data out of range", i));
+        if (!bf16_finite(off[0], cout * k) || !f32_finite(off[1], cout)) return fail(fmt("layer %zu holds a non-finite value", i));
     }
     return FAV_OK;
 }
@@ -1939,9 +1937,9 @@ fav_status classify_on_stream(fav_handle* h, const void* images, int32_t n, int3
     h->ev_used = h->profiling ? h->ev_used : 0;
     if (h->vit) {
         for (auto& L : h->layers) { L.w = L.w_m[0]; L.b = L.b_m[0]; }
-        // the batch in FAV_VIT_STREAMS (default 2) parts on as many streams: at 197 rows per frame every GEMM of the encoder is a
+        // the batch in fav_config.vit_streams (default 2) parts on as many streams: at 197 rows per frame every GEMM of the encoder is a
         // few hundred tiles, and the partial last round of one part's launch is filled by another part's (1: one stream)
-        static const int vit_streams = [] { const char* e = getenv("FAV_VIT_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+        const int vit_streams = h->cfg.vit_streams <= 0 ? 2 : std::min(4, (int)h->cfg.vit_streams);
         if (vit_streams > 1 && n >= 8 * vit_streams) {
             if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             while ((int)h->vit_streams.size() < vit_streams) {

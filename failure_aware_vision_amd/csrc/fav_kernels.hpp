@@ -20,7 +20,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
 // round-to-nearest-even fp32 -> bf16 bits (same integer recipe as the oracle;
-// no NaN can reach it on this path: inputs are finite pixels and weights)
+// no NaN can reach it on this path: pixels are sanitised where they enter (fav_sanitize_px), weights are checked finite when loaded)
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     uint32_t u = __float_as_uint(f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -33,6 +33,14 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// fp32 frames come from the caller: a NaN pixel counts as 0, everything else is clamped to [-64, 64] (far outside any image range;
+// pixels in [0, 1] pass unchanged), so that no garbage frame can put a NaN or an infinity into the network - the reference's seam
+// answers a bad frame with a status, never an exception (signal_analyzer.py:145-171).  oracle/fav_oracle.py: sanitize_pixels().
+__device__ __forceinline__ float fav_sanitize_px(float px) {
+    px = px == px ? px : 0.f;
+    return fminf(fmaxf(px, -64.f), 64.f);
 }
 
 // ---------------------------------------------------------------------------
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
                     const long long off = ((img * H + ih) * W + iw) * 3 + c;
                     float px;
                     if (LAYOUT == 0) px = __fmul_rn((float)((const uint8_t*)images)[off], 1.0f / 255.0f);
-                    else px = ((const float*)images)[off];
+                    else px = fav_sanitize_px(((const float*)images)[off]);
                     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
                     const float istd = c == 0 ? i0 : (c == 1 ? i1 : i2);
                     val = __fmul_rn(__fsub_rn(px, mean), istd);
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256) void stem_im2col_rows_kernel(const void* __res
                 if (ok) {
                     float px;
                     if (LAYOUT == 0) px = __fmul_rn((float)((const uint8_t*)images)[base + sx * 3 + c], 1.0f / 255.0f);
-                    else px = ((const float*)images)[base + sx * 3 + c];
+                    else px = fav_sanitize_px(((const float*)images)[base + sx * 3 + c]);
                     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
                     const float istd = c == 0 ? i0 : (c == 1 ? i1 : i2);
                     val = __fmul_rn(__fsub_rn(px, mean), istd);
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void stem7_pool_kernel(StemPoolParams p) {
 #pragma unroll
             for (int i = 0; i < NFILL; ++i) {
                 if (2 * i + 1 >= PROWS && frow0 != 0) break;     // 39 rows: the odd rows stop one short
-                const float px = LAYOUT == 0 ? __fmul_rn((float)pv[i], 1.0f / 255.0f) : __uint_as_float(pv[i]);
+                const float px = LAYOUT == 0 ? __fmul_rn((float)pv[i], 1.0f / 255.0f) : fav_sanitize_px(__uint_as_float(pv[i]));
                 const float val = (pok >> i & 1) ? __fmul_rn(__fsub_rn(px, fmean), fistd) : 0.f;
                 const uint16_t hb = (uint16_t)pack_bf16x2(val, 0.f);
 #pragma unroll

@@ -39,7 +39,13 @@ def classify_sharded(classifier, local_frames, n_total: int, rank: int, world: i
     this rank's slot of the all-gather send buffer (``Backend.classify_records``), one ``all_gather_into_tensor``
     (RCCL) moves them, and the results are views of the receive buffer - no pack, pad or concatenate launches.
     A plain function ``classify_fn(frames, first_index=...) -> (labels, conf)`` is accepted too (CPU tensors / gloo:
-    the tests that stand the oracle in for the per-rank classifier)."""
+    the tests that stand the oracle in for the per-rank classifier), and a ``Backend`` handed HOST frames (a NumPy
+    array, or a tensor that is not on its GPU) goes through its ordinary ``classify`` (which uploads them).
+
+    Lifetime of the results: on the direct path with equal shards (and with ``world == 1``) the two tensors are stride-2
+    VIEWS of one freshly allocated [n, 2] int32 record buffer - no copy is made; call ``.contiguous()`` before handing a raw
+    ``data_ptr()`` to something that assumes dense arrays.  Every call allocates its own buffers, so results stay valid
+    across later calls."""
     import torch
     import torch.distributed as dist
     start, stop = shard_range(n_total, rank, world)
@@ -47,7 +53,11 @@ def classify_sharded(classifier, local_frames, n_total: int, rank: int, world: i
     if n_local > 0 and int(local_frames.shape[0]) != n_local:
         raise ValueError(f"rank {rank} owns frames [{start},{stop}) but was handed {int(local_frames.shape[0])}")
     cap = -(-n_total // world)  # every shard padded to the largest
-    direct = hasattr(classifier, "classify_records")
+    direct = hasattr(classifier, "classify_records") and hasattr(local_frames, "is_cuda") and bool(local_frames.is_cuda) and \
+        local_frames.device.index == getattr(classifier, "device", local_frames.device.index)
+    if not direct and hasattr(classifier, "classify_records"):
+        backend = classifier
+        classifier = lambda frames, first_index=0: backend.classify(frames, first_index=first_index)   # noqa: E731  (host frames: upload + classify)
     if direct:
         dev = local_frames.device
         send = torch.empty((cap, 2), dtype=torch.int32, device=dev) if n_local == cap else \

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FAV_ABI_VERSION 1
+#define FAV_ABI_VERSION 2
 
 typedef struct fav_handle fav_handle;
 
@@ -81,6 +81,14 @@ typedef struct fav_config {
     int32_t regroup_block;  /* first residual block of the low-resolution group (-1 = auto) */
     int32_t n_members;      /* deep ensemble: independently trained checkpoints whose softmax is averaged
                                (1 = single model; > 1 excludes MC-Dropout) */
+    /* Schedule choices (ABI 2).  0 = this build's measured default; they never change a result, only which launches compute it
+     * (the library reads no environment variable). */
+    int32_t tail_min_rows;  /* layers 3-4 run their one-block-per-CU fused tails when the planned launch (max_batch x T x H x W
+                               rows, x members when grouped) has at least this many rows; 0 = 131 072; -1 = at any size */
+    int32_t ens_grouped_max;/* deep ensemble: calls of up to this many frames run every op as ONE launch over all members;
+                               0 = every call; -1 = never (one stream per member) */
+    int32_t vit_streams;    /* ViT: parts of a call's batch run side by side on as many streams, 1 .. 4; 0 = 2 */
+    int32_t stem_fused;     /* ImageNet stem as one launch (normalise + 7x7/2 + ReLU + max pool); 0 = yes; -1 = three launches */
 } fav_config;
 
 /* Fills *cfg with the defaults (ImageNet mean/std, T=1, no dropout, tau=0.5). */

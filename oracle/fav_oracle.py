@@ -167,10 +167,20 @@ def parse_blob(blob: bytes) -> Model:
 # Layer primitives (NHWC)
 # ----------------------------------------------------------------------------
 
+def sanitize_pixels(x: np.ndarray) -> np.ndarray:
+    """fp32 frames as the library takes them in (fav_kernels.hpp: fav_sanitize_px): NaN -> 0, then clamped to [-64, 64];
+    pixels in [0, 1] pass unchanged.  The reference answers a garbage frame with a status, never an exception
+    (signal_analyzer.py:145-171); here it cannot poison the network with non-finite values."""
+    x = np.asarray(x, np.float32)
+    return np.clip(np.where(np.isnan(x), np.float32(0), x), np.float32(-64), np.float32(64)).astype(np.float32)
+
+
 def normalize_input(x, mean, inv_std) -> np.ndarray:
     """[B,H,W,3] uint8 (0..255) or fp32 in [0,1] -> normalised bf16 values."""
     if x.dtype == np.uint8:
         x = x.astype(np.float32) * np.float32(1.0 / 255.0)
+    else:
+        x = sanitize_pixels(x)
     x = x.astype(np.float32)
     y = (x - np.asarray(mean, np.float32)) * np.asarray(inv_std, np.float32)
     return bf16_round(y)

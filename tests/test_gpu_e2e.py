@@ -216,6 +216,35 @@ def test_error_behaviour(r18_blob):
     be.close()
 
 
+@pytest.mark.parametrize("arch,hw", [("resnet18_cifar", 32), ("resnet50", 64)])
+def test_garbage_fp32_frames_stay_finite_and_match_the_sanitised_oracle(r18_blob, r50_blob, arch, hw):
+    """Caller-supplied fp32 frames with NaN / +-Inf / 1e30 pixels: the library treats NaN as 0 and clamps to [-64, 64]
+    (fav_sanitize_px, in all three stem kernels: CIFAR im2col, ImageNet fused stem, ViT patches share the im2col), so labels and
+    confidences stay finite and equal the oracle's on the sanitised frames bit for bit in the validation mode - the reference's seam
+    answers a garbage frame with a status, never an exception (signal_analyzer.py:145-171, video_source.py:76-78)."""
+    blob, _ = r18_blob if arch == "resnet18_cifar" else r50_blob
+    rng = np.random.default_rng(5)
+    x = rng.random((4, hw, hw, 3), dtype=np.float32)
+    x[0, 3, 4, 1] = np.nan; x[0, 0, 0, 0] = np.inf; x[1, hw - 1, hw - 1, 2] = -np.inf; x[2, 5, 5, :] = 1e30; x[2, 6, 6, 0] = -1e30
+    x[3, :, :, :] = np.nan                                          # a whole frame of NaNs = a black frame
+    be = Backend(arch, blob, max_batch=4, in_hw=(hw, hw), math_mode="f32_exact")
+    labels, conf = be.classify(torch.from_numpy(x).cuda())
+    logits = be.logits().cpu().numpy()
+    assert np.isfinite(logits).all() and torch.isfinite(conf).all()
+    model = O.parse_blob(blob)
+    ol, oc, olg, _ = O.classify(model, O.sanitize_pixels(x), O.ClassifyConfig(exact=True), return_logits=True)
+    assert np.array_equal(logits, olg)
+    ol2, oc2, olg2, _ = O.classify(model, x, O.ClassifyConfig(exact=True), return_logits=True)     # the oracle sanitises by itself, too
+    assert np.array_equal(olg2, olg)
+    zero = np.zeros((1, hw, hw, 3), np.float32)
+    assert np.array_equal(logits[0, 3], O.classify(model, zero, O.ClassifyConfig(exact=True), return_logits=True)[2][0, 0])
+    be.close()
+    fast = Backend(arch, blob, max_batch=4, in_hw=(hw, hw))          # production mode: finite as well
+    fl, fc = fast.classify(torch.from_numpy(x).cuda())
+    assert torch.isfinite(fast.logits()).all() and torch.isfinite(fc).all()
+    fast.close()
+
+
 def test_one_call_scorer_at_the_seam(r50_blob):
     """main.py:160-168 with the drop-in: ONE Backend.analyze_frame call per 240x320 frame returns the rule status of
     the reference's scorer (checked against its CPU restatement) AND the classifier's anomaly score, in the

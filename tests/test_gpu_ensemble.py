@@ -93,15 +93,14 @@ def test_ens5_per_gpu_share_properties(r50_members):
 
 @pytest.mark.parametrize("n", [5, 32, 70])
 def test_ens5_grouped_launches_equal_member_streams(r50_members, n, monkeypatch):
-    """The two ways a 5-member call runs - every op ONE launch over all members (block row = member; default for calls of
-    up to 64 frames) and one stream per member (larger calls) - give the same logits bit for bit, labels and confidences
-    included; FAV_ENS_GROUPED = frame limit of the grouped form, read when the handle is created (0: never)."""
+    """The two ways a 5-member call runs - every op ONE launch over all members (block row = member; the default for every
+    call) and one stream per member (fav_config.ens_grouped_max = -1, or calls beyond a positive limit) - give the same logits
+    bit for bit, labels and confidences included."""
     x = torch.from_numpy(frames_np(300, n)).cuda()
     blobs = [b for b, _ in r50_members]
     out = {}
     for limit in ("0", "4096"):
-        monkeypatch.setenv("FAV_ENS_GROUPED", limit)
-        be = Backend("resnet50", blobs, max_batch=n)
+        be = Backend("resnet50", blobs, max_batch=n, ens_grouped_max=-1 if limit == "0" else int(limit))
         labels, conf = be.classify(x, first_index=300)
         out[limit] = (labels.clone(), conf.clone(), be.logits().clone())
         if limit == "4096":            # a second, smaller call on the same handle (strides follow the call's n)

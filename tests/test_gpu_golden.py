@@ -48,19 +48,17 @@ def frame_crc(lg):
     return np.array([zlib.crc32(np.ascontiguousarray(lg[:, i, :]).tobytes()) for i in range(lg.shape[1])], np.uint32)
 
 
-@pytest.mark.parametrize("n,min_rows,n_wide", [(16, None, 0), (16, "0", 8), (64, None, 5)])
+@pytest.mark.parametrize("n,min_rows,n_wide", [(16, 0, 0), (16, -1, 8), (64, 0, 5)])
 def test_production_mode_mc_dropout_t30_fixture(r50_blob, monkeypatch, n, min_rows, n_wide):
     """BASELINE configs[2] (T=30, all_blocks, p=0.1, noise severity 3) in PRODUCTION bf16 mode on 64 frames:
     all 30 x 1000 logits of every frame bit-identical to the MFMA-model oracle.  16 frames run the schedule of a small
-    batch; FAV_TAIL_MIN_ROWS=0 plans them like the 256-frame headline (layer 3's conv_b + conv_c launch and layer 4's
+    batch; fav_config.tail_min_rows = -1 plans them like the 256-frame headline (layer 3's conv_b + conv_c launch and layer 4's
     row-owning expand, which the executor otherwise keeps for launches that fill the chip); 64 x 30 virtual frames get
     layer 3's fused launches by themselves."""
     blob, info = r50_blob
     d = load("r50_mfma_mc30_64.npz", info)
     assert len(d["labels"]) == 64
-    if min_rows is not None:
-        monkeypatch.setenv("FAV_TAIL_MIN_ROWS", min_rows)
-    be = Backend("resnet50", blob, max_batch=n, n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    be = Backend("resnet50", blob, max_batch=n, n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4, tail_min_rows=min_rows)
     be.set_profiling(True)
     labels, conf = be.classify(frames(0, n))
     rows = be.get_op_profile()

@@ -42,7 +42,7 @@ def test_config_struct_layout_and_defaults(lib):
     assert np.allclose(list(c.mean), [0.485, 0.456, 0.406]) and np.allclose(list(c.stdev), [0.229, 0.224, 0.225])
     lib.fav_default_config(C.byref(c), _lib.ARCH_RESNET18_CIFAR)
     assert (c.num_classes, c.in_h) == (10, 32)
-    assert lib.fav_abi_version() == 1
+    assert lib.fav_abi_version() == 2
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -145,7 +145,7 @@ def test_plain_c_caller_links_and_reports_missing_gpu(lib, tmp_path):
     import torch
     exe = _build_c_example(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
-    assert r.returncode == 64 and "ABI version 1" in r.stderr
+    assert r.returncode == 64 and "ABI version 2" in r.stderr
     if torch.cuda.is_available():
         pytest.skip("GPU present: the classify run is covered by the gpu-marked test")
     (tmp_path / "w.favw").write_bytes(b"\0" * 64)
@@ -216,6 +216,28 @@ def test_check_blob_accepts_real_checkpoints_and_rejects_hostile_tables(lib, r18
     assert _check(lib, bytes(b))[0] == BAD
     b = bytearray(blob); b[0] ^= 0xFF
     assert _check(lib, bytes(b))[0] == BAD
+    # a non-finite weight or bias is refused: it would defeat the pixel sanitiser (NaN in, NaN out whatever the frame)
+    w_off, b_off = struct.unpack_from("<2Q", blob, 32 + 48 * 2 + 32)
+    for off, fmt_, val in ((w_off + 6, "<H", 0x7FC0), (w_off, "<H", 0xFF80), (b_off + 4, "<I", 0x7F800000), (b_off, "<I", 0xFFC00000)):
+        b = bytearray(blob)
+        struct.pack_into(fmt_, b, off, val)
+        st, msg = _check(lib, bytes(b))
+        assert st == BAD and "non-finite" in msg, (off, msg)
+
+
+def test_oracle_sanitises_fp32_pixels():
+    """fp32 frames: NaN -> 0, everything else clamped to [-64, 64], pixels in [0, 1] untouched (the GPU side: fav_sanitize_px;
+    reference behaviour mirrored: a garbage frame yields a status, never an exception, signal_analyzer.py:145-171)."""
+    import numpy as np
+    from oracle import fav_oracle as O
+    x = np.array([0.0, 1.0, 0.25, np.nan, np.inf, -np.inf, 1e30, -3e38, 64.0, -64.5], np.float32)
+    y = O.sanitize_pixels(x)
+    assert np.array_equal(y, np.array([0.0, 1.0, 0.25, 0.0, 64.0, -64.0, 64.0, -64.0, 64.0, -64.0], np.float32))
+    frames = np.random.default_rng(0).random((2, 8, 8, 3), dtype=np.float32)
+    assert np.array_equal(O.sanitize_pixels(frames), frames)
+    bad = frames.copy(); bad[0, 1, 2, 0] = np.nan; bad[1, 3, 3, 1] = np.inf
+    n = O.normalize_input(bad, (0.485, 0.456, 0.406), O.inv_std32((0.229, 0.224, 0.225)))
+    assert np.isfinite(n).all()
 
 
 # ---- bench.py launch logic (no GPU, no torch import in the parent) -------------------------------------------------
