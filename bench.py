@@ -45,7 +45,7 @@ VIT_B16_GMAC = 17.56
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 KERNEL_SOURCES = ("failure_aware_vision_amd/csrc/fav_kernels.hpp", "failure_aware_vision_amd/csrc/fav.hip")
-CONV_KERNELS = ("fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel + fav::entry_reduce_kernel "
+CONV_KERNELS = ("fav::conv_igemm_kernel + fav::conv3x3_halo_kernel + fav::bottleneck_tail_kernel + fav::entry_reduce_kernel + fav::stem7_pool_kernel "
                 "(every conv / fc launch of the timed steps)")
 
 

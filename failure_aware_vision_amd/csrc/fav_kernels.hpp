@@ -9,6 +9,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Phase stamps (per-block clocks written through ConvParams / TailParams / GemmSkParams::dbg) exist in the experiments build only
+// (make EXPERIMENTS=1): in the normal build the pointer is a compile-time null and every stamp folds away - left in as run-time
+// checks they cost the layer-4 tails 4-5 % and the layer-3 tails 1-2 % (register allocation; profiles/r4q_dbg_stamps_ab.txt).
+#ifdef FAV_EXPERIMENTS
+#define FAV_DBG(P) ((P).dbg)
+#else
+#define FAV_DBG(P) ((unsigned long long*)nullptr)
+#endif
+
 namespace fav {
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
@@ -546,7 +555,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull] = wall_clock64();
 
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (L2); give each XCD a
     // contiguous run of tiles, n fastest, so the A tile of one m is re-read from
@@ -749,7 +758,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     if (p.nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 1] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 1] = wall_clock64();
 
     int cur = 0, nxt = NS - 1;  // stage being read / stage being filled
     if constexpr (PP == 1) {
@@ -894,7 +903,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     // BEFORE the accumulators go through LDS so their latency hides behind the staging
     // barrier.  (The barrier that ended the K loop already separates the last fragment
     // reads from the first staging writes.)
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 2] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 2] = wall_clock64();
     if (EPI == 1) {
         // ---- epilogue in registers (see the comment above the kernel) -----------------------------------------
         const int pr = wm * 64 + frow;                       // pixel row of b = 0 inside the tile
@@ -1058,9 +1067,9 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
         }
     }
     }
-    if (p.dbg) {
+    if (FAV_DBG(p)) {
         __syncthreads();
-        if (tid == 0) p.dbg[blockIdx.x * 4ull + 3] = wall_clock64();
+        if (tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 3] = wall_clock64();
     }
 }
 
@@ -1133,7 +1142,7 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int m0 = tile * BM;
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull] = wall_clock64();
     if (tid < BN) bias_s[(tid >> 4) * 20 + (tid & 15)] = p.bias[tid];
     if (tid < 64) ((uint32_t*)(hsm + zero_off))[tid] = 0u;
 
@@ -1215,7 +1224,7 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
     if (RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
     __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 1] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 1] = wall_clock64();
 
     int cur = 0, nxt = NS - 1;
     int tap = 0, cb = 0, tapoff = 0, tr = 0, ts = 0;        // tapoff = r*W + s
@@ -1291,7 +1300,7 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
     }
 #undef FAV_HSTAGE
     if (RESIDENT) __syncthreads();   // every wave is done with the patch before the staging overwrites it
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4ull + 2] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 2] = wall_clock64();
 
     // ---- epilogue: GROWS rows at a time through LDS (over the patch), 16 channels per thread ----
     constexpr int NCH = BN / 16;
@@ -1333,9 +1342,9 @@ __global__ __launch_bounds__(BM * 2, OCC) void conv3x3_halo_kernel(const ConvPar
             yo[1] = make_uint4(o[4], o[5], o[6], o[7]);
         }
     }
-    if (p.dbg) {
+    if (FAV_DBG(p)) {
         __syncthreads();
-        if (tid == 0) p.dbg[blockIdx.x * 4ull + 3] = wall_clock64();
+        if (tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 3] = wall_clock64();
     }
 }
 
@@ -1504,7 +1513,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
     }
     const int m0 = tile * BM;
     const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull] = wall_clock64();
 
     // ---- P0: biases, descriptors, the first requests ----------------------------------------------------------------
     // The bias values are REQUESTED here, all at once, and written to LDS only after the first LDS-DMA requests are out:
@@ -1645,7 +1654,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             FAV_T_BIAS_TO_LDS(true, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
+            if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 1] = wall_clock64();
             int cur = 0;
             for (int kt = 0; kt < NKT; ++kt) {
                 const unsigned char* As = tsm + cur * STG;
@@ -1731,7 +1740,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         FAV_T_BIAS_TO_LDS(true, true);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * BR) : "memory");
         __syncthreads();
-        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 1] = wall_clock64();
+        if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 1] = wall_clock64();
         int cur = 0, nxt = NS - 1;
         int tap = 0, cb = 0, tapoff = 0, tr = 0, ts = 0;
         for (int kt = 0; kt < NKT; ++kt) {
@@ -1782,7 +1791,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 #undef FAV_T_HSTAGE
         }
         if (NRED > 0 && !WA0_EARLY) FAV_T_STAGE_WA(0);
-        if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 2] = wall_clock64();
+        if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 2] = wall_clock64();
         // ---- P1e: T2 = bf16(relu(acc + bias_b)) -> LDS [BM][CMID], operand layout (every wave is past the patch) ----
 #pragma unroll
         for (int a = 0; a < TN1; ++a)
@@ -1843,7 +1852,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first chunk's weights (and the fragments)
         __syncthreads();
     }
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 3] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 3] = wall_clock64();
 
     // ---- P2 ---------------------------------------------------------------------------------------------------
     // lane (frow, fq) finishes channels 64j + 16fq .. + 15 of pixel rows wave*RP + b*16 + frow
@@ -1874,7 +1883,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
         const unsigned char* const wab = tsm + (((j + 1) & 1) ? p.wa_off1 : p.wa_off0);
         // residual of THIS chunk has landed; then the requests of the NEXT chunk (the other weight buffers: every
         // wave is past chunk j-1, the barrier at its end says so)
-        if ((j == 1 || j == 2) && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + (j == 1 ? 12 : 14)] = __builtin_amdgcn_s_memtime();
+        if ((j == 1 || j == 2) && FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + (j == 1 ? 12 : 14)] = __builtin_amdgcn_s_memtime();
         if (HAS_RES) {
 #pragma unroll
             for (int b = 0; b < TM2; ++b) {
@@ -1883,7 +1892,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 rcur[b][1] = rnext[b][1];
             }
         }
-        if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(rcur[TM2 - 1][1])); p.dbg[blockIdx.x * 16ull + 13] = __builtin_amdgcn_s_memtime(); }
+        if (j == 1 && FAV_DBG(p) && tid == 0) { asm volatile("s_nop 0" :: "v"(rcur[TM2 - 1][1])); FAV_DBG(p)[blockIdx.x * 16ull + 13] = __builtin_amdgcn_s_memtime(); }
         if (j + 1 < NCHUNK) {
             if (BARQ == 2) {
                 if ((j & 1) == 0 && j + 2 < NCHUNK) { FAV_T_STAGE_WC(j + 2); FAV_T_STAGE_WC(j + 3); }
@@ -1891,7 +1900,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             if (NRED > 0) FAV_T_STAGE_WA(j + 1);
             FAV_T_LOAD_RES(j + 1)
         }
-        if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 6] = __builtin_amdgcn_s_memtime();
+        if (j == 1 && FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 6] = __builtin_amdgcn_s_memtime();
         // -- A: acc2 = T2 x Wc[j]^T : RP pixels x 64 channels
         f32x4_t acc2[4][TM2];
 #pragma unroll
@@ -1916,7 +1925,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                     acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc2[a][b], 0, 0, 0);
                 }
         }
-        if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(acc2[3][TM2 - 1])); p.dbg[blockIdx.x * 16ull + 7] = __builtin_amdgcn_s_memtime(); }
+        if (j == 1 && FAV_DBG(p) && tid == 0) { asm volatile("s_nop 0" :: "v"(acc2[3][TM2 - 1])); FAV_DBG(p)[blockIdx.x * 16ull + 7] = __builtin_amdgcn_s_memtime(); }
         if (!WC2 && j + 1 < NCHUNK) {      // single Wc buffer: every wave has read Wc[j], the next chunk's may overwrite it
             FAV_BAR();
             FAV_T_STAGE_WC(j + 1);
@@ -1981,7 +1990,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 }
             }
         }
-        if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 8] = __builtin_amdgcn_s_memtime();
+        if (j == 1 && FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 8] = __builtin_amdgcn_s_memtime();
         // -- C: acc3 += Ychunk (this wave's own rows: its LDS writes are in order, no barrier) x Wa[:, 64j .. 64j+63]^T
         if constexpr (LINEST) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2022,16 +2031,16 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 }
             }
         }
-        if (j == 1 && p.dbg && tid == 0) { asm volatile("s_nop 0" :: "v"(acc3[NA3 - 1][TM2 - 1])); p.dbg[blockIdx.x * 16ull + 9] = __builtin_amdgcn_s_memtime(); }
+        if (j == 1 && FAV_DBG(p) && tid == 0) { asm volatile("s_nop 0" :: "v"(acc3[NA3 - 1][TM2 - 1])); FAV_DBG(p)[blockIdx.x * 16ull + 9] = __builtin_amdgcn_s_memtime(); }
         // the next chunk's weight pieces of this wave have landed (its residual loads and this chunk's stores stay in
         // flight), then the barrier publishes every wave's pieces and retires this chunk's reads of the current buffers
         if (j + 1 < NCHUNK && (BARQ == 1 || (j & 1))) {
             // WC2: the youngest operations are the next residual loads and this chunk's stores; otherwise the Wc pieces
             // were issued after the residual loads, so only the stores may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WC2 && HAS_RES) ? 4 * TM2 : 2 * TM2) : "memory");
-            if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 10] = __builtin_amdgcn_s_memtime();
+            if (j == 1 && FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 10] = __builtin_amdgcn_s_memtime();
             FAV_BAR();
-            if (j == 1 && p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 11] = __builtin_amdgcn_s_memtime();
+            if (j == 1 && FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 11] = __builtin_amdgcn_s_memtime();
         }
     }
 #undef FAV_T_LOAD_RES
@@ -2039,7 +2048,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
 #undef FAV_T_STAGE_WA
 #undef FAV_T_BIAS_TO_LDS
 
-    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16ull + 4] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 4] = wall_clock64();
     // ---- P3: t1' = bf16(relu(acc3 + bias_a)): lane holds channels 64*g3 + 16fq .. + 15 of its pixel rows ----------
     if constexpr (NRED > 0) {
         const __amdgpu_buffer_rsrc_t srd_t =
@@ -2066,9 +2075,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
             }
         }
     }
-    if (p.dbg) {
+    if (FAV_DBG(p)) {
         __syncthreads();
-        if (tid == 0) p.dbg[blockIdx.x * 16ull + 5] = wall_clock64();
+        if (tid == 0) FAV_DBG(p)[blockIdx.x * 16ull + 5] = wall_clock64();
     }
 }
 #undef FAV_BAR
@@ -2524,12 +2533,12 @@ __global__ __launch_bounds__(256, 3) void gemm_streamk_kernel(const GemmSkParams
     int e_prev = 0;                                  // vector-memory operations issued in the previous iteration behind its stage
     int slot = 0;
     unsigned long long dsum[5] = {0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
-    if (p.dbg && tid == 0) p.dbg[wg * 8ull + 6] = wall_clock64();
+    if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[wg * 8ull + 6] = wall_clock64();
     for (int i = 0; i < nsteps; ++i) {
         int np = 0;
-        if (p.dbg) dt0 = __builtin_amdgcn_s_memtime();
+        if (FAV_DBG(p)) dt0 = __builtin_amdgcn_s_memtime();
         if (i + 2 < nsteps) { const int s2 = slot == 0 ? 2 : slot - 1; FAV_SK_STAGE(s2, np); }
-        if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[0] += dt1 - dt0; dt0 = dt1; }
+        if (FAV_DBG(p)) { dt1 = __builtin_amdgcn_s_memtime(); dsum[0] += dt1 - dt0; dt0 = dt1; }
         int e_cur = 0;
         const int tg = tx0 + ctile;
         const int tm = (int)fastdiv((uint32_t)tg, p.div_tn), tn = tg - tm * p.tiles_n;
@@ -2607,7 +2616,7 @@ __global__ __launch_bounds__(256, 3) void gemm_streamk_kernel(const GemmSkParams
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[a][b], 0, 0, 0);
                 }
         }
-        if (p.dbg) { asm volatile("s_nop 0" :: "v"(acc[TN - 1][TM - 1])); dt1 = __builtin_amdgcn_s_memtime(); dsum[1] += dt1 - dt0; dt0 = dt1; }
+        if (FAV_DBG(p)) { asm volatile("s_nop 0" :: "v"(acc[TN - 1][TM - 1])); dt1 = __builtin_amdgcn_s_memtime(); dsum[1] += dt1 - dt0; dt0 = dt1; }
         // ---- end of a segment: epilogue, or publish the partial accumulator ----------------------------------------------------
         if (++ck == ckb) {
             if (ckb == p.ksteps) {
@@ -2670,23 +2679,23 @@ __global__ __launch_bounds__(256, 3) void gemm_streamk_kernel(const GemmSkParams
             if (++cj < nseg) { FAV_SK_SEG(cj, ctile, ck, ckb); cfirst = true; }
         }
         // ---- step i + 1 has landed: everything issued behind its stage may stay in flight ----------------------------------------
-        if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[2] += dt1 - dt0; dt0 = dt1; }
+        if (FAV_DBG(p)) { dt1 = __builtin_amdgcn_s_memtime(); dsum[2] += dt1 - dt0; dt0 = dt1; }
         if (i + 1 < nsteps) {
             sk_wait_vmcnt(e_prev + np + e_cur);
-            if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[3] += dt1 - dt0; dt0 = dt1; }
+            if (FAV_DBG(p)) { dt1 = __builtin_amdgcn_s_memtime(); dsum[3] += dt1 - dt0; dt0 = dt1; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (p.dbg) { dt1 = __builtin_amdgcn_s_memtime(); dsum[4] += dt1 - dt0; dt0 = dt1; }
+            if (FAV_DBG(p)) { dt1 = __builtin_amdgcn_s_memtime(); dsum[4] += dt1 - dt0; dt0 = dt1; }
         }
         e_prev = e_cur;
         slot = slot == 2 ? 0 : slot + 1;
     }
-    if (p.dbg && tid == 0) {
+    if (FAV_DBG(p) && tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) p.dbg[wg * 8ull + k] = dsum[k];
-        p.dbg[wg * 8ull + 5] = (unsigned long long)nsteps;
-        p.dbg[wg * 8ull + 7] = wall_clock64();
+        for (int k = 0; k < 5; ++k) FAV_DBG(p)[wg * 8ull + k] = dsum[k];
+        FAV_DBG(p)[wg * 8ull + 5] = (unsigned long long)nsteps;
+        FAV_DBG(p)[wg * 8ull + 7] = wall_clock64();
     }
 #undef FAV_SK_STAGE
 #undef FAV_SK_PTILE
