@@ -468,7 +468,10 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const int epi = epi_forced >= 0 ? epi_forced : ((d.res && !big) ? 0 : 1);
 #define FAV_LAUNCH(BN_, BK_, NS_, MODE_)                                                                          \
     do {                                                                                                          \
-        if (epi) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 1>), grid, dim3(256), 0, s, p); \
+        if (d.relu == 2) {      /* GELU (ViT MLP): the instantiations that carry it */                            \
+            if (epi) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 1, 0, true>), grid, dim3(256), 0, s, p); \
+            else hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 0, 0, true>), grid, dim3(256), 0, s, p);     \
+        } else if (epi) hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 1>), grid, dim3(256), 0, s, p); \
         else hipLaunchKernelGGL((conv_igemm_kernel<128, BN_, BK_, NS_, MODE_, 2, 0, 0>), grid, dim3(256), 0, s, p);     \
     } while (0)
 #define FAV_LAUNCH_MODE(MODE_)                                                                    \
@@ -479,7 +482,11 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
 #define FAV_LAUNCH_BIG(MODE_)                                                                                     \
     do {                                                                                                          \
         const int pp = (int)FAV_KNOB("FAV_CONV_PP", 1);                                                           \
-        if (epi && pp && MODE_ == 0) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0, 2, 0, 1, 1>), grid, dim3(512), 0, s, p); \
+        if (d.relu == 2) {                                                                                        \
+            if (epi && pp && MODE_ == 0) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0, 2, 0, 1, 1, true>), grid, dim3(512), 0, s, p); \
+            else if (epi) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 1, 0, true>), grid, dim3(512), 0, s, p);    \
+            else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 0, 0, true>), grid, dim3(512), 0, s, p);        \
+        } else if (epi && pp && MODE_ == 0) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, 0, 2, 0, 1, 1>), grid, dim3(512), 0, s, p); \
         else if (epi) hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 1>), grid, dim3(512), 0, s, p);    \
         else hipLaunchKernelGGL((conv_igemm_kernel<256, 256, 64, 2, MODE_, 2, 0, 0>), grid, dim3(512), 0, s, p);        \
     } while (0)

@@ -530,7 +530,9 @@ constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
 // GELU, Philox dropout (one call = exactly its 16 draws) and the bf16 rounding need no fp32 staging through LDS and no
 // barrier.  (Tiles with 32 columns per wave use 32-row groups and 8 channels per lane.)  The sums are unchanged - an
 // output element still meets its products in ascending k.  EPI = 0 is the round-1 epilogue through an fp32 LDS stage.
-template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1, int PP = 0>
+// GELU: the tanh-form GELU epilogue (ViT MLP) is compiled in.  The ResNet launches use the instantiations without it: ~40 vector
+// instructions per element that never run still cost the 250-register kernels their schedule.
+template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1, int PP = 0, bool GELU = false>
 __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p_launch) {
     const ConvParams p = conv_group_params(p_launch);
     constexpr int NT = (BM / 64) * WN * 64;     // threads: (BM/64) x WN waves, each a 64 x BN/WN sub-tile
@@ -960,7 +962,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                     if (p.relu == 1) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                    } else if (p.relu == 2) {
+                    } else if (GELU && p.relu == 2) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = fav_gelu(v[k]);
                     }
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                 if (p.relu == 1) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                } else if (p.relu == 2) {   // tanh-form GELU (ViT MLP)
+                } else if (GELU && p.relu == 2) {   // tanh-form GELU (ViT MLP)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fav_gelu(v[j]);
                 }
