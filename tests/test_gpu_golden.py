@@ -95,6 +95,53 @@ def test_headline_config_vs_independent_torch_cpu(r50_blob):
     assert len(np.unique(ref)) >= 12
 
 
+def test_headline_config_two_batches_mfma_model_fixture(r50_blob):
+    """The HEADLINE config on two of its own batches: 512 corrupted frames x T = 30 (all_blocks, p = 0.1), production bf16 mode,
+    the launch sequence bench.py times - all 30 x 1000 logits of every frame bit-identical to the MFMA-model oracle (per-frame
+    CRC-32; fixture: make_classifier_fixtures.py mfma_mc512, ~2.6 h of the oracle on 5 cores), labels exactly equal.  The second
+    batch starts at global frame 256, so the Philox keys of a call that does not start at frame 0 are covered at full size."""
+    blob, info = r50_blob
+    d = load("r50_mfma_mc30_512.npz", info)
+    n = len(d["labels"])
+    assert n == 512
+    be = Backend("resnet50", blob, max_batch=256, n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    crc, lab, cf = [], [], []
+    for s0 in (0, 256):
+        labels, conf = be.classify(frames(s0, 256), first_index=s0)
+        crc.append(frame_crc(be.logits())); lab.append(labels.cpu().numpy()); cf.append(conf.cpu().numpy())
+    be.close()
+    crc, lab, cf = np.concatenate(crc), np.concatenate(lab), np.concatenate(cf)
+    assert np.array_equal(crc, d["logit_crc32"]), f"{int((crc != d['logit_crc32']).sum())} of {n} frames differ"
+    tie = d["gap"] < 1e-6
+    assert np.array_equal(lab[~tie], d["labels"].astype(np.int32)[~tie])
+    np.testing.assert_allclose(cf, d["conf"], rtol=0, atol=3e-6)
+    note(f"headline config vs the MFMA-model oracle: {n} / {n} frames with all 30 x 1000 logits bit-identical, {len(np.unique(lab))} distinct labels")
+    assert len(np.unique(lab)) > 20
+
+
+def test_headline_config_1000_frames_vs_independent_torch_cpu(r50_blob):
+    """The headline config against the oracle that knows nothing of the MFMA adder (oracle/torch_cpu.py) on 1 000 corrupted frames,
+    T = 30 (fixture: make_torchcpu_mc_fixture.py 1000): labels may differ only where the oracle's own top-2 gap is below 0.01."""
+    blob, info = r50_blob
+    d = load("r50_torchcpu_mc30_1000.npz", info)
+    n = len(d["labels"])
+    assert n == 1000
+    be = Backend("resnet50", blob, max_batch=256, n_samples=30, dropout_policy="all_blocks", dropout_p=0.1, seed=4)
+    lab, cf = [], []
+    for s0 in range(0, n, 250):
+        labels, conf = be.classify(frames(s0, 250), first_index=s0)
+        lab.append(labels.cpu().numpy()); cf.append(conf.cpu().numpy())
+    be.close()
+    lg, cg = np.concatenate(lab), np.concatenate(cf)
+    ref, gap = d["labels"].astype(np.int32), d["gap"]
+    bad = lg != ref
+    note(f"headline config vs torch-CPU ({n} frames, T = 30): {n - bad.sum()} / {n} labels equal; largest top-2 gap among the "
+         f"disagreements {gap[bad].max() if bad.any() else 0:.4f}; max |dconf| {np.abs(cg - d['conf']).max():.4f}")
+    assert np.all(gap[bad] < 0.01), gap[bad]
+    assert bad.sum() <= 0.02 * n
+    assert np.abs(cg - d["conf"]).max() < 0.02
+
+
 def test_vit_b16_production_mode_fixture():
     """BASELINE configs[4]: ViT-B/16 on 64 corrupted 224x224 frames (the per-GPU share of its global batch), entropy confidence at temperature 1.5,
     PRODUCTION bf16 mode: every logit bit-identical to the fixture (per-frame CRC-32), labels exactly equal."""
