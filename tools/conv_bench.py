@@ -1,4 +1,5 @@
-"""Micro-benchmark of representative ResNet-50 conv shapes through fav_op_conv2d."""
+"""Micro-benchmark of representative ResNet-50 conv shapes through fav_op_conv2d.  (FAV_* knobs - tile forcing, phase clocks - exist in the
+experiments build only: make -C failure_aware_vision_amd/csrc EXPERIMENTS=1.)"""
 import ctypes as C, os, sys, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

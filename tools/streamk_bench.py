@@ -1,5 +1,7 @@
 """The ViT encoder's four linear layers at the per-GPU share of BASELINE configs[4] (64 frames: 12 608 rows) and at 512 frames:
-chained stream-K GEMM (fav_op_linear_streamk) against the tile-per-block kernel (fav_op_conv2d), same tensors, bit-compared."""
+chained stream-K GEMM (fav_op_linear_streamk) against the tile-per-block kernel (fav_op_conv2d), same tensors, bit-compared.
+With the experiments build (make EXPERIMENTS=1): FAV_CONV_BIG=0 FAV_CONV_BK=32 makes the tile kernel the encoder's 128 x 128 x 32 form, FAV_SK_DBG=1
+prints where a stream-K step's ticks go, FAV_SK_NOHANDOFF=1 times it without its hand-offs (wrong results)."""
 import ctypes as C, os, sys, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

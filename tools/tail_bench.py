@@ -1,5 +1,6 @@
 """Micro-benchmark of the fused bottleneck tail (fav_op_bottleneck_tail) against the separate launches it replaces,
-same process, same tensors, results compared bit for bit.  FAV_CONV_DBG=1 adds per-block phase clocks."""
+same process, same tensors, results compared bit for bit.  FAV_CONV_DBG=1 adds per-block phase clocks (FAV_CONV_DBG_DUMP=file: the raw
+stamps for tools/phase_overlap.py) - like every FAV_* knob that needs the experiments build: make -C failure_aware_vision_amd/csrc EXPERIMENTS=1."""
 import ctypes as C, os, sys, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
