@@ -370,14 +370,16 @@ const char* launch_conv(fav_handle* h, const fav_conv_desc& d, int cout_pad, int
     const fav_handle::Group G = h ? h->grp : fav_handle::Group{};
     p.g_x = G.x; p.g_w = G.w; p.g_bias = G.b; p.g_res = G.res; p.g_y = G.y;
     if (d.out_f32 && p.drop.site >= 0) return "conv: dropout on fp32 output unsupported";
-    // the ViT encoder's GEMMs (M = 197 rows per frame, K = 768 / 3072, 64 frames per call): measured on MI355X
-    // (profiles/r2g_vit_knobs.txt) 128-row tiles with 32-deep steps at three blocks per CU beat the 256 x 256 tile (the GELU
-    // epilogue has nothing to hide behind at one block per CU) and the 64-deep steps (594 tiles do not fill 2 x 256 slots twice)
+    // the ViT encoder's GEMMs (M = 197 rows per frame, K = 768 / 3072): the 256 x 256 tile from 50 of them up (measured, round 4,
+    // tools/experiments/r4_vit_tiles.sh: +18 % at 128 frames on two streams, +1.5 % at the 64-frame share; since the GELU epilogue
+    // shrank to 14 instructions per element it no longer needs a second block per CU to hide behind); below that 128-row tiles with
+    // 32-deep steps at three blocks per CU
     const bool vit = h && h->vit;
-    // ViT: the 256 x 256 tile only for launches with >= FAV_VIT_BIG_TILES of them (default: never at the per-GPU share of 64 frames, see below)
-    const long long vit_big_tiles = FAV_KNOB("FAV_VIT_BIG_TILES", 512);
-    const bool vit_big = vit && (M / 256) * (cout_pad / 256) >= vit_big_tiles;
-    const bool big = (!vit || vit_big) && conv_big(d.kh, d.kw, M * G.n, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
+    const long long vit_big_tiles = FAV_KNOB("FAV_VIT_BIG_TILES", 50);
+    const bool vit_big = vit && cout_pad % 256 == 0 && d.kh * d.kw * d.Cin >= 512 && (M / 256) * (cout_pad / 256) >= vit_big_tiles &&
+                         FAV_KNOB("FAV_CONV_BIG", 2) != 0;
+    const bool big = vit ? vit_big
+                         : conv_big(d.kh, d.kw, M * G.n, cout_pad, d.kh * d.kw * d.Cin, d.res != nullptr);   // 256 x 256 x 64 tile, 8 waves, 128 KB of LDS
     const int BN = big ? 256 : ((cout_pad % 128 == 0) ? 128 : 64);
     const int BK = big ? 64 : (vit ? 32 : conv_bk(d.kh, d.kw, d.kh * d.kw * d.Cin, d.res != nullptr));
     const int BM = big ? 256 : 128;   // (256-row tiles with 128 columns lose to two blocks per CU of 128-row tiles on every 3x3 shape)
@@ -941,16 +943,18 @@ bool launch_gemm_streamk(fav_handle* h, const void* a, const void* w, const floa
 
 const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, int T, int D, int heads, int math_mode, hipStream_t s) {
     if (T < 1 || T > 256 || heads * 64 != D || n < 1) return "attention: need 1 <= tokens <= 256 and 64-wide heads";
-    const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32, vstride = Tp2 * 2 + 16;
-    // one wave per query tile if their P strips fit beside K and V (197 tokens: 13 waves, 152 KB), else 8 waves round robin
-    int nw = nkt > 8 ? nkt : 8;
-    if (nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride > 160 * 1024) nw = 8;
-    const int attn_nw = (int)FAV_KNOB("FAV_ATTN_WAVES", 0);   // experiments build: 8 forces the old shape
-    if (attn_nw == 8) nw = 8;
-    const int lds = nkt * 16 * 128 + Tp2 * 128 + nw * 16 * vstride;
+    const int nkt = (T + 15) / 16, Tp2 = (T + 31) / 32 * 32;
+    // as few rounds of query tiles as 8 waves allow, then as few waves as those rounds need (197 tokens: 13 tiles = 2 rounds of 7
+    // waves); K and V are all the LDS a block holds (55 KB), so two blocks share a CU
+    const int rounds = (nkt + 7) / 8;
+    int nw = (nkt + rounds - 1) / rounds;
+    const int attn_nw = (int)FAV_KNOB("FAV_ATTN_WAVES", 0);   // experiments build: another block shape
+    if (attn_nw >= 1 && attn_nw <= 8) nw = attn_nw;
+    const int lds = nkt * 16 * 128 + Tp2 * 128;
     static DeviceFlags attr_set;
     if (!attr_set.test_current()) {
-        if (hipFuncSetAttribute((const void*)attention_kernel<0, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)attention_kernel<0, 13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attention_kernel<0, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)attention_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)attention_kernel<1, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)attention_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -960,8 +964,8 @@ const char* launch_attention(fav_handle* h, const void* qkv, void* out, int n, i
     const double flops = 4.0 * n * heads * (double)T * T * 64;
     Prof pr(h, s, FAV_K_CONV, flops, (double)n * T * D * 2 * 4);
     const dim3 grid((unsigned)(n * heads)), block(nw * 64);
-#define FAV_ATTN(MODE_, NKT_) hipLaunchKernelGGL((attention_kernel<MODE_, NKT_>), grid, block, lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads)
-    if (math_mode == FAV_MATH_BF16) { if (nkt <= 13) FAV_ATTN(0, 13); else FAV_ATTN(0, 16); }
+#define FAV_ATTN(MODE_, ...) hipLaunchKernelGGL((attention_kernel<MODE_, __VA_ARGS__>), grid, block, lds, s, (const uint16_t*)qkv, (uint16_t*)out, T, D, heads)
+    if (math_mode == FAV_MATH_BF16) { if (nkt == 13) FAV_ATTN(0, 13, true); else if (nkt < 13) FAV_ATTN(0, 13); else FAV_ATTN(0, 16); }
     else { if (nkt <= 13) FAV_ATTN(1, 13); else FAV_ATTN(1, 16); }
 #undef FAV_ATTN
     return nullptr;

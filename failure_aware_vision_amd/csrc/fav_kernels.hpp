@@ -53,9 +53,9 @@ __device__ __forceinline__ float fav_sanitize_px(float px) {
 }
 
 // ---------------------------------------------------------------------------
-// exp and tanh-form GELU as fixed sequences of IEEE fp32 operations (the ViT path).  The CPU
+// exp and GELU as fixed sequences of IEEE fp32 operations (the ViT path).  The CPU
 // oracle (oracle/fav_exact.c: fav_expf_ref, fav_gelu_ref) executes the same sequence, so the
-// results are bit-identical; libm's expf / tanhf would differ by an ulp here and there.
+// results are bit-identical; libm's expf / erff would differ by an ulp here and there.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float fav_expf(float x) {
     if (!(x >= -80.0f)) return 0.0f;   // also NaN -> 0; keeps every result a normal number
@@ -76,13 +76,24 @@ __device__ __forceinline__ float fav_expf(float x) {
 // (measured: 11 % of random inputs differ from IEEE), so go through the correctly rounded f64 root - rounding
 // that to fp32 is exact-rounded as well (53 >= 2*24 + 2 bits).
 __device__ __forceinline__ float fav_sqrtf(float x) { return (float)sqrt((double)x); }
+// GELU(x) = x * Phi(x) with the normal CDF (the erf form, torch.nn.GELU's default) as a fixed polynomial:
+// Phi(x) = 0.5 + u q(u^2 - 0.5), u = clamp(x, +-4.5) / 4.5, q of degree 9 (Horner, fused), fitted so that
+// |x Phi(x) - GELU(x)| <= 1.6e-5 everywhere and Phi(+-4.5) rounds to exactly 1 / 0.  14 vector instructions; the
+// exp-and-divide tanh form it replaced cost ~40 and was 30 x further from the erf form (4.7e-4).
 __device__ __forceinline__ float fav_gelu(float x) {
-    const float x3 = __fmul_rn(__fmul_rn(x, x), x);
-    const float inner = __fadd_rn(x, __fmul_rn(0x1.6e4e26p-5f, x3));
-    const float z = __fmul_rn(0x1.988454p-1f, inner);
-    const float e = fav_expf(__fadd_rn(z, z));
-    const float t = __fsub_rn(1.0f, __fdiv_rn(2.0f, __fadd_rn(e, 1.0f)));
-    return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, t));
+    const float u = __fmul_rn(__builtin_amdgcn_fmed3f(x, -4.5f, 4.5f), 0x1.c71c72p-3f);
+    const float s = __fmaf_rn(u, u, -0.5f);
+    float q = -0x1.1e4aacp+1f;
+    q = __fmaf_rn(q, s, 0x1.3a20d0p+2f);
+    q = __fmaf_rn(q, s, -0x1.1e092ep+2f);
+    q = __fmaf_rn(q, s, 0x1.8d38d8p+1f);
+    q = __fmaf_rn(q, s, -0x1.430d8cp+1f);
+    q = __fmaf_rn(q, s, 0x1.04f2dap+1f);
+    q = __fmaf_rn(q, s, -0x1.749848p+0f);
+    q = __fmaf_rn(q, s, 0x1.f84810p-1f);
+    q = __fmaf_rn(q, s, -0x1.63a098p-1f);
+    q = __fmaf_rn(q, s, 0x1.6981eap-1f);
+    return __fmul_rn(x, __fmaf_rn(u, q, 0.5f));
 }
 
 // Philox4x32-10 (Random123).  counter = (chunk, frame, sample, site), key = seed.
@@ -478,7 +489,7 @@ struct ConvParams {
     int kw, stride, pad;
     int M;          // n_frames * Ho * Wo
     int K, nk;      // K = kh*kw*Cin, nk = K / BK
-    int relu, out_f32;   // relu: 0 none, 1 ReLU, 2 tanh-form GELU
+    int relu, out_f32;   // relu: 0 none, 1 ReLU, 2 GELU
     int tiles_m, tiles_n;
     int stage_mid;  // issue a 64-deep step's DMA after its first MFMA group (3x3) or in front (1x1)
     DropParams drop;
@@ -530,7 +541,7 @@ constexpr int conv_waves_per_simd(int BM, int BN, int BK, int NS) {
 // GELU, Philox dropout (one call = exactly its 16 draws) and the bf16 rounding need no fp32 staging through LDS and no
 // barrier.  (Tiles with 32 columns per wave use 32-row groups and 8 channels per lane.)  The sums are unchanged - an
 // output element still meets its products in ascending k.  EPI = 0 is the round-1 epilogue through an fp32 LDS stage.
-// GELU: the tanh-form GELU epilogue (ViT MLP) is compiled in.  The ResNet launches use the instantiations without it: ~40 vector
+// GELU: the GELU epilogue (ViT MLP) is compiled in.  The ResNet launches use the instantiations without it: ~40 vector
 // instructions per element that never run still cost the 250-register kernels their schedule.
 template <int BM, int BN, int BK, int NS, int MODE, int WN = 2, int OCCW = 0, int EPI = 1, int PP = 0, bool GELU = false>
 __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_simd(BM, BN, BK, NS)) void conv_igemm_kernel(const ConvParams p_launch) {
@@ -1045,7 +1056,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                 if (p.relu == 1) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                } else if (GELU && p.relu == 2) {   // tanh-form GELU (ViT MLP)
+                } else if (GELU && p.relu == 2) {   // GELU (ViT MLP)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fav_gelu(v[j]);
                 }
@@ -2400,7 +2411,7 @@ struct GemmSkParams {
     uint16_t* y;              // [M][N] bf16
     int M, N, K, ksteps;      // ksteps = K / 32
     int tiles_n, tiles;       // tiles = ceil(M / 128) * (N / 128)
-    int act;                  // 0 none, 2 tanh-form GELU
+    int act;                  // 0 none, 2 GELU
     int Q;                    // workgroups per XCD group; grid = 8 Q
     float* ws;                // [grid][16][256] float4: partial accumulators
     uint32_t* flags;          // [grid]: == epoch once the slot is published
@@ -2782,53 +2793,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     }
 }
 
-// Multi-head attention, head width 64, up to 256 tokens: one block (8 waves) per (frame, head).
+// Multi-head attention, head width 64, up to 256 tokens: one block per (frame, head), two blocks per CU.
 //   qkv [n][T][3D] bf16 (Q | K | V, head h = columns 64h..64h+63 of each)  ->  out [n][T][D] bf16
-// K and V live in LDS, both row-major (whole 16-byte chunks, XOR-swizzled); the second product's A operand - V^T, eight
-// consecutive keys of one channel per lane - is read with gfx950's transposing ds_read_b64_tr_b16 (two per fragment), so
-// nothing is scattered while staging.  A wave takes 16 queries at a time:
-//   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), x 1/8, keys >= T masked,
-//   row max / sum by the lane (sequential over its keys) and two xor-shuffles, e = fav_expf(s - max),
-//   p = e * (1 / sum) rounded to bf16 through a per-wave LDS strip, O = V^T P^T on MFMA over keys ascending.
-// The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate.
-// The block has one wave per query tile when the P strips of that many waves fit in LDS (197 tokens: 13 waves, one
-// pass, every wave busy), else 8 waves that take the tiles round robin.
+// K and V live in LDS, both row-major (whole 16-byte chunks, XOR-swizzled), 55 KB for 197 tokens - nothing else does, so two
+// blocks share a CU and one stages its K / V while the other computes.  A wave takes 16 queries at a time (197 tokens: 7 waves,
+// two tiles each):
+//   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), x 1/8, keys >= T masked (last key tile only),
+//   row max by the lane and two xor-shuffles, e = exp(s - max) two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32; the
+//   same IEEE operations as fav_expf), row sum = two interleaved partial sums per lane, then the shuffles,
+//   p = e * (1 / sum) rounded to bf16 IN REGISTERS: the S accumulator layout (4 consecutive keys per lane and key tile) is used
+//   directly as the B operand of O = V^T P^T, whose k slot 8g + j of 32-key block b therefore holds key 32b + 16 (j >> 2) + 4g +
+//   (j & 3) - a fixed permutation of the keys inside each block that the A operand follows: V^T comes out of LDS through gfx950's
+//   transposing ds_read_b64_tr_b16, two per fragment, at rows 4g.. and 16 + 4g...  No P strip in LDS, no round trip.
+// The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate (attn_key_order there).
 typedef short attn_v4s __attribute__((ext_vector_type(4)));
-// XOR on the 16-byte chunk index of V's 128-byte rows: the 8 rows x 32 bytes a 32-lane half of a transposed read touches
-// (rows r .. r+3 and r+8 .. r+11 of one 16-channel column pair) fall on 64 different banks; even, so a pair stays a pair
-__device__ __forceinline__ int attn_vsw(int row) { return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// XOR on the 16-byte chunk index of V's 128-byte rows: the 8 consecutive rows x 32 bytes a 32-lane half of a transposed read
+// touches fall on 64 different banks (rows two apart would share them); even, so a chunk pair stays a pair
+__device__ __forceinline__ int attn_vsw(int row) { return 2 * ((row >> 1) & 3); }
 
-// NKT = key tiles the kernel is built for (T <= 16 NKT): 13 for ViT-B/16's 197 tokens - 12 score registers fewer than 16, which is
-// what keeps the 16-wave block (128 registers per wave) free of scratch.
-template <int MODE, int NKT = 16>
-__global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
-                                                         int heads) {
+// exp of two non-positive numbers (or -inf): per element the operations of fav_expf, minus its upper clamp, which x <= 0 never takes
+__device__ __forceinline__ f32x2_t fav_expf_nonpos2(f32x2_t x) {
+    const f32x2_t t = x * (f32x2_t){0x1.715476p+0f, 0x1.715476p+0f};
+    const f32x2_t k = {rintf(t.x), rintf(t.y)};
+    f32x2_t r = __builtin_elementwise_fma(-k, (f32x2_t){0x1.62e400p-1f, 0x1.62e400p-1f}, x);
+    r = __builtin_elementwise_fma(-k, (f32x2_t){0x1.7f7d1cp-20f, 0x1.7f7d1cp-20f}, r);
+    f32x2_t p = __builtin_elementwise_fma((f32x2_t){0x1.6c16c2p-10f, 0x1.6c16c2p-10f}, r, (f32x2_t){0x1.111112p-7f, 0x1.111112p-7f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){0x1.555556p-5f, 0x1.555556p-5f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){0x1.555556p-3f, 0x1.555556p-3f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){0.5f, 0.5f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){1.0f, 1.0f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){1.0f, 1.0f});
+    f32x2_t e;
+    e.x = x.x >= -80.0f ? ldexpf(p.x, (int)k.x) : 0.0f;
+    e.y = x.y >= -80.0f ? ldexpf(p.y, (int)k.y) : 0.0f;
+    return e;
+}
+
+// NKT = key tiles the kernel is built for (T <= 16 NKT): 13 for ViT-B/16's 197 tokens, 12 score registers fewer than 16.
+// FULL: T needs exactly NKT tiles, so every tile guard and the position of the masked tile are compile-time (the production shape).
+template <int MODE, int NKT = 16, bool FULL = false>
+__global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int D,
+                                                           int heads) {
     extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
-    const int nkt = (T + 15) >> 4;             // key tiles of 16
-    const int Tp2 = ((T + 31) >> 5) << 5;      // keys padded for the 32-deep second product
-    const int vstride = Tp2 * 2 + 16;          // bytes per P row (the +16 spreads rows over the banks)
+    const int nkt = FULL ? NKT : (T + 15) >> 4;                    // key tiles of 16
+    const int Tp2 = FULL ? (NKT + 1) / 2 * 32 : ((T + 31) >> 5) << 5;   // keys padded for the 32-deep second product
     unsigned char* const Ks = asm_;                                   // [nkt*16][128 B], chunk ^= row & 7
     unsigned char* const Vs = Ks + nkt * 16 * 128;                    // [Tp2][128 B], chunk ^= attn_vsw(row)
-    unsigned char* const Ps = Vs + Tp2 * 128;                         // [waves][16][vstride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthr = blockDim.x, nwaves = nthr >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int h = blockIdx.x % heads;
     const long long f = blockIdx.x / heads;
     const uint16_t* base = qkv + f * (long long)T * 3 * D;
-    const int nqt = (T + 15) >> 4;
+    const int nqt = nkt;
     // the Q fragments of this wave's first query tile: requested before anything else
-    uint4 fq0[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    uint4 fqn[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
     if (wave < nqt && wave * 16 + frow < T) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fq0[kk] = *(const uint4*)(base + (long long)(wave * 16 + frow) * 3 * D + h * 64 + kk * 32 + fq * 8);
+        for (int kk = 0; kk < 2; ++kk) fqn[kk] = *(const uint4*)(base + (long long)(wave * 16 + frow) * 3 * D + h * 64 + kk * 32 + fq * 8);
     }
-    // ---- stage K and V (zero beyond T): every global load first, then the LDS writes (at most 4 rounds: 256 keys, >= 512 threads)
-    {
+    // ---- stage K and V (zero beyond T): four (K, V) chunk pairs per thread in flight, then their LDS writes
+    for (int c0 = 0; c0 < Tp2 * 8; c0 += 4 * nthr) {
         uint4 kv[4], vv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = tid + r * nthr, row = i >> 3, ch = i & 7;
+            const int i = c0 + tid + r * nthr, row = i >> 3, ch = i & 7;
             kv[r] = make_uint4(0u, 0u, 0u, 0u);
             vv[r] = make_uint4(0u, 0u, 0u, 0u);
             if (row < T) {
@@ -2838,29 +2868,28 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = tid + r * nthr, row = i >> 3, ch = i & 7;
+            const int i = c0 + tid + r * nthr, row = i >> 3, ch = i & 7;
             if (row < nkt * 16) *(uint4*)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = kv[r];
             if (row < Tp2) *(uint4*)(Vs + row * 128 + ((ch ^ attn_vsw(row)) << 4)) = vv[r];
         }
     }
-    unsigned char* const Pw = Ps + wave * 16 * vstride;
-    for (int i = lane; i < 16 * (vstride / 16); i += 64) *(uint4*)(Pw + i * 16) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     // transposed reads of V: lane 4q + p of a 16-lane group addresses row (key) r0 + q, channels 4p .. 4p + 3 of the block
     const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const int vsw_l = attn_vsw(8 * fq + tq);       // = attn_vsw of every row this lane addresses (rows 32*ks + 8*fq + tq (+ 4))
-    const unsigned char* const vbase = Vs + (8 * fq + tq) * 128 + ((tp >> 1) << 4) + 8 * (tp & 1);
+    const int vsw_l = attn_vsw(4 * fq + tq);       // = attn_vsw of every row this lane addresses (rows 32*ks + 4*fq + tq (+ 16))
+    const unsigned char* const vbase = Vs + (4 * fq + tq) * 128 + ((tp >> 1) << 4) + 8 * (tp & 1);
 
     for (int qt = wave; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + frow;          // this lane's query (as MFMA column)
-        uint4 fqv[2];
+        const uint4 fqv[2] = {fqn[0], fqn[1]};
+        {   // the next tile's Q fragments travel while this one is computed
+            const int q2 = q + nwaves * 16;
+            fqn[0] = make_uint4(0u, 0u, 0u, 0u);
+            fqn[1] = make_uint4(0u, 0u, 0u, 0u);
+            if (qt + nwaves < nqt && q2 < T) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            fqv[kk] = fq0[kk];
-            if (qt != wave) {
-                fqv[kk] = make_uint4(0u, 0u, 0u, 0u);
-                if (q < T) fqv[kk] = *(const uint4*)(base + (long long)q * 3 * D + h * 64 + kk * 32 + fq * 8);
+                for (int kk = 0; kk < 2; ++kk) fqn[kk] = *(const uint4*)(base + (long long)q2 * 3 * D + h * 64 + kk * 32 + fq * 8);
             }
         }
         f32x4_t sc[NKT];
@@ -2887,73 +2916,87 @@ __global__ __launch_bounds__(1024) void attention_kernel(const uint16_t* __restr
                     }
                 }
             }
+            // straight-line code (FULL): without a fence the scheduler hoists every K fragment read to the top - 104 registers
+            if (FULL && (kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        // scale, mask, row max
+        // scale, mask (only the last key tile reaches past T), row max
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + fq * 4 + r;
-                    const float v = key < T ? __fmul_rn(sc[kt][r], 0.125f) : -INFINITY;
-                    sc[kt][r] = v;
-                    mx = fmaxf(mx, v);
+                f32x2_t lo = {sc[kt][0], sc[kt][1]}, hi = {sc[kt][2], sc[kt][3]};
+                lo = lo * (f32x2_t){0.125f, 0.125f};
+                hi = hi * (f32x2_t){0.125f, 0.125f};
+                if (FULL ? kt == NKT - 1 : kt == nkt - 1) {
+                    const int key = kt * 16 + fq * 4;
+                    lo.x = key < T ? lo.x : -INFINITY;
+                    lo.y = key + 1 < T ? lo.y : -INFINITY;
+                    hi.x = key + 2 < T ? hi.x : -INFINITY;
+                    hi.y = key + 3 < T ? hi.y : -INFINITY;
                 }
+                sc[kt] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};
+                mx = fmaxf(fmaxf(mx, lo.x), lo.y);     // v_max3_f32
+                mx = fmaxf(fmaxf(mx, hi.x), hi.y);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+        const f32x2_t nmx = {-mx, -mx};
+        f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = fav_expf(__fsub_rn(sc[kt][r], mx));
-                    sc[kt][r] = e;
-                    sum = __fadd_rn(sum, e);
-                }
+                const f32x2_t lo = fav_expf_nonpos2((f32x2_t){sc[kt][0], sc[kt][1]} + nmx);
+                const f32x2_t hi = fav_expf_nonpos2((f32x2_t){sc[kt][2], sc[kt][3]} + nmx);
+                sum2 = sum2 + lo;
+                sum2 = sum2 + hi;
+                sc[kt] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};
             }
+        float sum = __fadd_rn(sum2.x, sum2.y);
         sum = __fadd_rn(sum, __shfl_xor(sum, 16, 64));
         sum = __fadd_rn(sum, __shfl_xor(sum, 32, 64));
         const float inv_sum = __fdiv_rn(1.0f, sum);   // one IEEE division per query row, then multiplications
+        const f32x2_t inv2 = {inv_sum, inv_sum};
+        uint2 pk[NKT + 1];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-            if (kt < nkt) {
-                const float p0 = __fmul_rn(sc[kt][0], inv_sum), p1 = __fmul_rn(sc[kt][1], inv_sum);
-                const float p2 = __fmul_rn(sc[kt][2], inv_sum), p3 = __fmul_rn(sc[kt][3], inv_sum);
-                *(uint2*)(Pw + frow * vstride + (kt * 16 + fq * 4) * 2) = make_uint2(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3));
+        for (int kt = 0; kt <= NKT; ++kt) {
+            pk[kt] = make_uint2(0u, 0u);
+            if (kt < NKT && kt < nkt) {
+                const f32x2_t lo = (f32x2_t){sc[kt][0], sc[kt][1]} * inv2, hi = (f32x2_t){sc[kt][2], sc[kt][3]} * inv2;
+                pk[kt] = make_uint2(pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y));
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is private to this wave: LDS ops are in order, no barrier
+        }
         f32x4_t oc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < (Tp2 >> 5); ++ks) {
-            const uint4 fp = *(const uint4*)(Pw + frow * vstride + (ks * 32 + fq * 8) * 2);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                // V^T fragment: channel dt*16 + frow, keys 32*ks + 8*fq .. + 7 = two transposed 4-key x 16-channel blocks
-                const unsigned char* va = vbase + ks * 4096 + (((2 * dt) ^ vsw_l) << 4);
-                const attn_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_v4s*)(va));
-                const attn_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_v4s*)(va + 512));
-                const uint2 t0u = __builtin_bit_cast(uint2, t0), t1u = __builtin_bit_cast(uint2, t1);
-                const uint4 fv = make_uint4(t0u.x, t0u.y, t1u.x, t1u.y);
-                if (MODE == 0) {
-                    union { uint4 u; bf16x8_t v; } ua, ub;
-                    ua.u = fv; ub.u = fp;
-                    oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, oc[dt], 0, 0, 0);
-                } else {
+        for (int ks = 0; ks < (NKT + 1) / 2; ++ks)
+            if (ks < (Tp2 >> 5)) {
+                // P^T fragment: query frow, k slots 8 fq .. + 7 = keys 32 ks + 4 fq .. + 3 and 32 ks + 16 + 4 fq .. + 3
+                const uint4 fp = make_uint4(pk[2 * ks].x, pk[2 * ks].y, pk[2 * ks + 1].x, pk[2 * ks + 1].y);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t wa = ((const uint32_t*)&fv)[j >> 1], xa = ((const uint32_t*)&fp)[j >> 1];
-                        const float wf = bf16_bits_to_f32((j & 1) ? (wa >> 16) : (wa & 0xFFFFu));
-                        const float xf = bf16_bits_to_f32((j & 1) ? (xa >> 16) : (xa & 0xFFFFu));
-                        oc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf, oc[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) {
+                    // V^T fragment: channel dt*16 + frow at the same keys = two transposed 4-key x 16-channel blocks, 16 rows apart
+                    const unsigned char* va = vbase + ks * 4096 + (((2 * dt) ^ vsw_l) << 4);
+                    const attn_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_v4s*)(va));
+                    const attn_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_v4s*)(va + 2048));
+                    const uint2 t0u = __builtin_bit_cast(uint2, t0), t1u = __builtin_bit_cast(uint2, t1);
+                    const uint4 fv = make_uint4(t0u.x, t0u.y, t1u.x, t1u.y);
+                    if (MODE == 0) {
+                        union { uint4 u; bf16x8_t v; } ua, ub;
+                        ua.u = fv; ub.u = fp;
+                        oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, oc[dt], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t wa = ((const uint32_t*)&fv)[j >> 1], xa = ((const uint32_t*)&fp)[j >> 1];
+                            const float wf = bf16_bits_to_f32((j & 1) ? (wa >> 16) : (wa & 0xFFFFu));
+                            const float xf = bf16_bits_to_f32((j & 1) ? (xa >> 16) : (xa & 0xFFFFu));
+                            oc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xf, oc[dt], 0, 0, 0);
+                        }
                     }
                 }
+                if (FULL && (ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of the strip are done before the next tile overwrites it
         if (q < T) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)

@@ -134,7 +134,7 @@ def _conv64(x, w, stride, pad):
 def make_synthetic_vit(arch="vit_b16", seed: int = 1, num_classes: int = 1000, in_hw=None,
                        mean=DEFAULT_MEAN, std=DEFAULT_STD, logit_std: float = 5.0):
     """Seeded synthetic ViT checkpoint (pre-norm encoder, class token, learned positions,
-    tanh-GELU MLP).  LayerNorm keeps activations in range, so no calibration pass is needed:
+    GELU MLP).  LayerNorm keeps activations in range, so no calibration pass is needed:
     linear layers are N(0, 1/fan_in) (x0.5 where they feed the residual stream) and the head is
     scaled for logits of standard deviation `logit_std`.  Returns (blob, info)."""
     aid = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
@@ -402,7 +402,8 @@ def from_state_dict(arch, sd, num_classes: int | None = None, bn_eps: float = 1e
     * ``vit_b16`` / ``vit_tiny``: timm naming (``patch_embed.proj``, ``cls_token``, ``pos_embed``, ``blocks.i.norm1``,
       ``attn.qkv``, ``attn.proj``, ``norm2``, ``mlp.fc1``, ``mlp.fc2``, ``norm``, ``head``); qkv rows are
       Q | K | V with head h in rows 64h..64h+63 of each, the class token is added into row 0 of the position table.
-      The device MLP uses the tanh form of GELU.
+      The device MLP uses the erf form of GELU (torch.nn.GELU's default, what timm checkpoints are trained with)
+      through a fixed polynomial for the normal CDF, within 1.6e-5 of it.
     """
     aid = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
     specs, folded = [], []

@@ -188,7 +188,7 @@ typedef struct fav_conv_desc {
     const void* res;         /* optional [n_frames][Ho][Wo][Cout] bf16 */
     void* y;                 /* [n_frames][Ho][Wo][Cout] bf16, or fp32 if out_f32 */
     int32_t n_frames, H, W, Cin, Cout, kh, kw, stride, pad;
-    int32_t relu, out_f32, math_mode;   /* relu: 0 = none, 1 = ReLU, 2 = tanh-form GELU (ViT MLP) */
+    int32_t relu, out_f32, math_mode;   /* relu: 0 = none, 1 = ReLU, 2 = GELU (ViT MLP) */
     fav_dropout_desc drop;
 } fav_conv_desc;
 fav_status fav_op_conv2d(const fav_conv_desc* d, void* hip_stream);
@@ -250,7 +250,7 @@ fav_status fav_op_layernorm(const void* x, int64_t ldx, const float* gamma, cons
 fav_status fav_op_attention(const void* qkv, void* out, int32_t n, int32_t T, int32_t D, int32_t heads,
                             int32_t math_mode, void* hip_stream);
 /* One linear layer of the encoder as the chained stream-K GEMM (gemm_streamk_kernel): y[rows][N] = act((x[rows][K] w[N][K]^T + bias) + res),
- * bf16 in and out, fp32 bias; res may be NULL or y itself (in-place residual); act 0 none, 1 ReLU, 2 tanh-form GELU.  Bit-identical to
+ * bf16 in and out, fp32 bias; res may be NULL or y itself (in-place residual); act 0 none, 1 ReLU, 2 GELU.  Bit-identical to
  * fav_op_conv2d with kh = kw = 1 on the same operands (the K steps are dealt out evenly over a persistent grid and a tile's partial
  * accumulator is handed on, never re-associated).  K % 32 == 0, N % 128 == 0, at least 256 tiles of 128 x 128; production math only.
  * No reference counterpart (the slot is platform/backend/main.py:160). */

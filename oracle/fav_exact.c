@@ -537,14 +537,17 @@ static inline float fav_expf_ref(float x) {
     return ldexpf(p, (int)k);
 }
 
-/* tanh-form GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), tanh(z) = 1 - 2 / (exp(2z) + 1) */
+/* GELU(x) = x Phi(x), Phi = the normal CDF (erf form, torch.nn.GELU's default), as a fixed polynomial:
+ * Phi(x) = 0.5 + u q(u^2 - 0.5), u = clamp(x, +-4.5) / 4.5, q of degree 9 in Horner form with fused multiply-adds
+ * (fitted: |x Phi(x) - GELU(x)| <= 1.6e-5; Phi(+-4.5) rounds to exactly 1 / 0, so GELU(x) = x or -0 beyond). */
 static inline float fav_gelu_ref(float x) {
-    const float x3 = (x * x) * x;
-    const float inner = x + 0x1.6e4e26p-5f * x3;
-    const float z = 0x1.988454p-1f * inner;
-    const float e = fav_expf_ref(z + z);
-    const float t = 1.0f - 2.0f / (e + 1.0f);
-    return (0.5f * x) * (1.0f + t);
+    static const float Q[10] = {0x1.6981eap-1f, -0x1.63a098p-1f, 0x1.f84810p-1f, -0x1.749848p+0f, 0x1.04f2dap+1f,
+                                -0x1.430d8cp+1f, 0x1.8d38d8p+1f, -0x1.1e092ep+2f, 0x1.3a20d0p+2f, -0x1.1e4aacp+1f};
+    const float u = fminf(fmaxf(x, -4.5f), 4.5f) * 0x1.c71c72p-3f;
+    const float s = fmaf(u, u, -0.5f);
+    float q = Q[9];
+    for (int j = 8; j >= 0; --j) q = fmaf(q, s, Q[j]);
+    return x * fmaf(u, q, 0.5f);
 }
 
 void fav_expf_arr(const float* x, float* y, long n) {
@@ -595,8 +598,9 @@ void fav_layernorm_rows(const float* x, const float* gamma, const float* beta, f
 }
 
 /* Attention softmax over rows of Tk scores (already scaled): the device holds, per query, keys
- * kt*16 + 4*fq + r in lane group fq (0..3); each group sums exp() of its keys in ascending
- * order, groups combine as (s0 + s1) + (s2 + s3).  p = e * (1 / sum): ONE correctly rounded reciprocal per row
+ * kt*16 + 4*fq + r in lane group fq (0..3); each group keeps two partial sums of exp(), even keys and odd keys (two
+ * elements per packed instruction), each in ascending key order, adds them, and the groups combine as (s0 + s1) +
+ * (s2 + s3).  p = e * (1 / sum): ONE correctly rounded reciprocal per row
  * and a multiplication per element (the device spends a VALU division only once per query). */
 void fav_attn_softmax_rows(const float* s, float* p, long rows, int Tk) {
 #pragma omp parallel for
@@ -604,13 +608,13 @@ void fav_attn_softmax_rows(const float* s, float* p, long rows, int Tk) {
         const float* sr = s + q * Tk;
         float mx = -INFINITY;
         for (int k = 0; k < Tk; ++k) mx = sr[k] > mx ? sr[k] : mx;
-        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float part[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
         for (int k = 0; k < Tk; ++k) {
             const float e = fav_expf_ref(sr[k] - mx);
             p[q * Tk + k] = e;
-            part[(k >> 2) & 3] = part[(k >> 2) & 3] + e;
+            part[(k >> 2) & 3][k & 1] = part[(k >> 2) & 3][k & 1] + e;
         }
-        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+        const float sum = ((part[0][0] + part[0][1]) + (part[1][0] + part[1][1])) + ((part[2][0] + part[2][1]) + (part[3][0] + part[3][1]));
         const float inv = 1.0f / sum;
         for (int k = 0; k < Tk; ++k) p[q * Tk + k] = p[q * Tk + k] * inv;
     }

@@ -482,7 +482,7 @@ CONF_ENTROPY = 1
 
 # ----------------------------------------------------------------------------
 # ViT-B/16 (BASELINE configs[4]).  Build-defined like the rest (PARITY UNPINNED): pre-norm
-# encoder, class token, learned positions, tanh-GELU MLP, bf16 at every tensor boundary,
+# encoder, class token, learned positions, GELU MLP, bf16 at every tensor boundary,
 # fp32 accumulation / statistics.  exp, GELU, LayerNorm and the attention softmax are the
 # exact fp32 operation sequences of oracle/fav_exact.c, which the HIP kernels repeat.
 # ----------------------------------------------------------------------------
@@ -539,20 +539,34 @@ def gemm_acc(a, w, exact=False):
     return conv_acc_exact(a.reshape(1, m, 1, kp), w.reshape(w.shape[0], 1, 1, kp), 1, 1, 1, 0, exact).reshape(m, w.shape[0])
 
 
+def attn_key_order(t):
+    """Key held by each k slot of the second product, O = P V: the device feeds the score accumulators (4 consecutive keys per
+    lane group g and 16-key tile) straight back as the MFMA operand, so slot 8g + j of 32-key block b holds key
+    32b + 16 (j >> 2) + 4g + (j & 3).  Returns the keys in slot order over ceil(t / 32) blocks (keys >= t are zero padding)."""
+    slot = np.arange((t + 31) // 32 * 32)
+    b, g, j = slot >> 5, (slot >> 3) & 3, slot & 7
+    return 32 * b + 16 * (j >> 2) + 4 * g + (j & 3)
+
+
 def attention(qkv, heads, exact=False):
     """qkv [B, T, 3D] bf16 values -> [B, T, D] bf16: per head softmax(Q K^T / 8) V with fp32
-    scores, probabilities rounded to bf16 before the second product."""
+    scores, probabilities rounded to bf16 before the second product, whose keys go through the
+    summation model in the device's slot order (attn_key_order)."""
     b, t, d3 = qkv.shape
     d = d3 // 3
     out = np.empty((b, t, d), np.float32)
+    order = attn_key_order(t)
+    pp = np.zeros((t, order.size), np.float32)
+    vp = np.zeros((order.size, 64), np.float32)
     for i in range(b):
         for h in range(heads):
             q = qkv[i, :, h * 64:(h + 1) * 64]
             k = qkv[i, :, d + h * 64:d + (h + 1) * 64]
             v = qkv[i, :, 2 * d + h * 64:2 * d + (h + 1) * 64]
             s = gemm_acc(q, k, exact) * np.float32(0.125)
-            p = bf16_round(attn_softmax_exact(s))
-            out[i, :, h * 64:(h + 1) * 64] = bf16_round(gemm_acc(p, np.ascontiguousarray(v.T), exact))
+            pp[:, :t] = bf16_round(attn_softmax_exact(s))
+            vp[:t] = v
+            out[i, :, h * 64:(h + 1) * 64] = bf16_round(gemm_acc(pp[:, order], np.ascontiguousarray(vp[order].T), exact))
     return out
 
 

@@ -1,4 +1,4 @@
-"""ViT-B/16 path (BASELINE configs[4]): attention (MFMA QK^T / softmax / V), LayerNorm, tanh-GELU MLP,
+"""ViT-B/16 path (BASELINE configs[4]): attention (MFMA QK^T / softmax / V), LayerNorm, GELU MLP,
 temperature-scaled entropy confidence.
 
 exp, GELU, LayerNorm and the attention softmax are fixed sequences of IEEE fp32 operations that
@@ -50,7 +50,7 @@ def test_layernorm_bitwise(lib, rows, D, stride_mul):
     assert np.array_equal(host_f32(y), exp)
 
 
-@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (3, 17, 2), (1, 256, 1), (2, 33, 3)])
+@pytest.mark.parametrize("n,T,heads", [(2, 197, 12), (3, 17, 2), (1, 256, 1), (2, 33, 3), (1, 208, 2), (2, 193, 1), (1, 1, 1), (1, 130, 2)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_attention_bitwise(lib, n, T, heads, mode):
     rng = np.random.default_rng(n * 1000 + T + heads)

@@ -23,8 +23,8 @@ def test_exact_exp_and_gelu_are_accurate():
     assert O.expf_exact(np.array([-81.0, -1e30, -np.inf], np.float32)).tolist() == [0.0, 0.0, 0.0]
     xg = np.linspace(-12, 12, 240001).astype(np.float32)
     g = O.gelu_exact(xg).astype(np.float64)
-    refg = F.gelu(torch.from_numpy(xg).double(), approximate="tanh").numpy()
-    assert np.max(np.abs(g - refg)) < 1e-6
+    refg = F.gelu(torch.from_numpy(xg).double()).numpy()              # the erf form, torch.nn.GELU's default
+    assert np.max(np.abs(g - refg)) < 2e-5
     assert O.gelu_exact(np.array([-30.0, 30.0], np.float32)).tolist() == [-0.0, 30.0]
 
 
@@ -59,7 +59,7 @@ def torch_vit_logits(model, xn):
         a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, -1, d)
         x = x + F.linear(a, t(proj.w).reshape(d, d), t(proj.b))
         y = F.layer_norm(x, (d,), t(ln2.w), t(ln2.b), 1e-6)
-        x = x + F.linear(F.gelu(F.linear(y, t(fc1.w).reshape(-1, d), t(fc1.b)), approximate="tanh"), t(fc2.w).reshape(d, -1), t(fc2.b))
+        x = x + F.linear(F.gelu(F.linear(y, t(fc1.w).reshape(-1, d), t(fc1.b))), t(fc2.w).reshape(d, -1), t(fc2.b))
     y = F.layer_norm(x[:, 0], (d,), t(Ls[li].w), t(Ls[li].b), 1e-6)
     return F.linear(y, t(Ls[li + 1].w).reshape(-1, d), t(Ls[li + 1].b)).numpy()
 

@@ -28,7 +28,7 @@ class _VitBlock(nn.Module):
         qkv = self.attn.qkv(self.norm1(x)).reshape(b, t, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
         att = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * (d // self.heads) ** -0.5, dim=-1)
         x = x + self.attn.proj((att @ qkv[2]).transpose(1, 2).reshape(b, t, d))
-        return x + self.mlp.fc2(nn.functional.gelu(self.mlp.fc1(self.norm2(x)), approximate="tanh"))
+        return x + self.mlp.fc2(nn.functional.gelu(self.mlp.fc1(self.norm2(x))))
 
 
 class VisionTransformer(nn.Module):
