@@ -2807,7 +2807,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 //   transposing ds_read_b64_tr_b16, two per fragment, at rows 4g.. and 16 + 4g...  No P strip in LDS, no round trip.
 // The operation order is the one oracle/fav_oracle.py: attention() + fav_attn_softmax_rows restate (attn_key_order there).
 typedef short attn_v4s __attribute__((ext_vector_type(4)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // XOR on the 16-byte chunk index of V's 128-byte rows: the 8 consecutive rows x 32 bytes a 32-lane half of a transposed read
 // touches fall on 64 different banks (rows two apart would share them); even, so a chunk pair stays a pair
 __device__ __forceinline__ int attn_vsw(int row) { return 2 * ((row >> 1) & 3); }
