@@ -23,6 +23,9 @@ SHAPES = [  # name, H, Cin, Cout, k, stride, res, drop
     ("T3c2 3x3s2 256->256 @28", 28, 256, 256, 3, 2, 0, 0),
     ("X L3c3 plain", 14, 256, 1024, 1, 1, 0, 0), ("X L3c3 +res", 14, 256, 1024, 1, 1, 1, 0), ("X L3c3 +drop", 14, 256, 1024, 1, 1, 0, 1),
     ("X L1c3 plain", 56, 64, 256, 1, 1, 0, 0), ("X L1c3 +res", 56, 64, 256, 1, 1, 1, 0), ("X L1c3 +drop", 56, 64, 256, 1, 1, 0, 1),
+    # ViT-B/16 linear layers: 197 rows per frame (H = 197, W = 1), --frames = frames per call
+    ("V qkv 768->2304", 197, 768, 2304, 1, 1, 0, 0), ("V proj 768->768 +res", 197, 768, 768, 1, 1, 1, 0),
+    ("V fc1 768->3072 gelu", 197, 768, 3072, 1, 1, 0, 0), ("V fc2 3072->768 +res", 197, 3072, 768, 1, 1, 1, 0),
 ]
 tot = 0.0
 for name, H, cin, cout, k, stride, res, drop in SHAPES:
@@ -30,23 +33,25 @@ for name, H, cin, cout, k, stride, res, drop in SHAPES:
     n = a.frames * (4 if H == 7 else 1)
     pad = k // 2
     Ho = (H + 2 * pad - k) // stride + 1
-    x = (torch.randn(n, H, H, cin, device="cuda") * 0.5).to(torch.bfloat16)
+    vit = name.startswith("V ")
+    W, Wo = (1, 1) if vit else (H, Ho)
+    x = (torch.randn(n, H, W, cin, device="cuda") * 0.5).to(torch.bfloat16)
     w = (torch.randn(cout, k, k, cin, device="cuda") * (2.0 / (k * k * cin)) ** 0.5).to(torch.bfloat16)
     b = torch.randn(cout, device="cuda") * 0.1
-    r = (torch.randn(n, Ho, Ho, cout, device="cuda")).to(torch.bfloat16) if res else None
-    y = torch.empty(n, Ho, Ho, cout, device="cuda", dtype=torch.bfloat16)
+    r = (torch.randn(n, Ho, Wo, cout, device="cuda")).to(torch.bfloat16) if res else None
+    y = torch.empty(n, Ho, Wo, cout, device="cuda", dtype=torch.bfloat16)
     dd = _lib.FavDropoutDesc(3 if drop else -1, 26, 1.0 / (1 - 26 / 256), 4, 0, 256, 0)
     d = _lib.FavConvDesc(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(),
-                         n, H, H, cin, cout, k, k, stride, pad, 1, 0, 0, dd)
+                         n, H, W, cin, cout, k, k, stride, pad, (2 if "gelu" in name else 0) if vit else 1, 0, 0, dd)
     for _ in range(2): _lib.check(lib.fav_op_conv2d(C.byref(d), None))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(a.iters): lib.fav_op_conv2d(C.byref(d), None)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    M = n * Ho * Ho
+    M = n * Ho * Wo
     fl = 2.0 * M * cout * k * k * cin
-    by = 2.0 * (n * H * H * cin + M * cout * (2 if res else 1) + cout * k * k * cin)
+    by = 2.0 * (n * H * W * cin + M * cout * (2 if res else 1) + cout * k * k * cin)
     # scale to the headline workload: 7680 virtual frames
     scale = 7680.0 / n
     tot += ms * scale
