@@ -290,3 +290,42 @@ def test_head_tie_breaks_to_lowest_index(lib):
                                conf.data_ptr(), None, None, None))
     torch.cuda.synchronize()
     assert labels.cpu().tolist() == [7, 0]
+
+
+# Launches large enough for the 256 x 256 ping-pong tile against the SAME operation on 32-frame slices, which take the 128-row tiles:
+# every tile kernel implements one k order, so the bits must agree whatever the tile and the grid - a size-independent property at a
+# size no CPU oracle reaches (and the check any other schedule of that tile has to pass: tools/experiments/r4_persistent_big_tile.diff).
+BIG_TILE_CASES = [
+    # cin, cout, k, H, W, frames, residual, relu, dropout
+    (512, 512, 1, 14, 14, 1024, True, 1, True),
+    (512, 512, 1, 14, 14, 1023, True, 1, False),      # a partial last tile, tile count not a multiple of the grid
+    (256, 256, 3, 14, 14, 1024, False, 1, True),
+    (768, 3072, 1, 197, 1, 512, False, 2, False),     # ViT fc1 + GELU
+    (768, 768, 1, 197, 1, 700, True, 0, False),       # ViT proj + residual
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W,n,use_res,relu,use_drop", BIG_TILE_CASES)
+def test_big_tile_matches_sliced_launches(lib, cin, cout, k, H, W, n, use_res, relu, use_drop):
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + k + n)
+    pad = k // 2
+    x = (torch.randn((n, H, W, cin), device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    w = (torch.randn((cout, k, k, cin), device="cuda", generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.bfloat16)
+    b = torch.randn((cout,), device="cuda", generator=g) * 0.2
+    res = torch.randn((n, H, W, cout), device="cuda", generator=g).to(torch.bfloat16) if use_res else None
+    y = torch.zeros((n, H, W, cout), dtype=torch.bfloat16, device="cuda")
+    y2 = torch.zeros_like(y)
+
+    def launch(lo, hi, out):
+        dd = drop_desc(3, 26, 1.0 / (1 - 26 / 256), 77, lo, n, 5) if use_drop else drop_desc()
+        d = _lib.FavConvDesc(x[lo:hi].data_ptr(), w.data_ptr(), b.data_ptr(), res[lo:hi].data_ptr() if use_res else None,
+                             out[lo:hi].data_ptr(), hi - lo, H, W, cin, cout, k, k, 1, pad, relu, 0, 0, dd)
+        _lib.check(lib.fav_op_conv2d(C.byref(d), None))
+
+    launch(0, n, y)
+    for lo in range(0, n, 32):
+        launch(lo, min(n, lo + 32), y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), \
+        f"{(y.view(torch.int16) != y2.view(torch.int16)).float().mean().item():.6f} of elements differ"
+    assert y.float().abs().sum().item() > 0
