@@ -919,6 +919,11 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
     if (FAV_DBG(p) && tid == 0) FAV_DBG(p)[blockIdx.x * 4ull + 2] = wall_clock64();
     if (EPI == 1) {
         // ---- epilogue in registers (see the comment above the kernel) -----------------------------------------
+        // LSTORE (the ping-pong tile): bf16 results go through a wave-private image in the K stages, which nobody reads after the loop's
+        // last barrier (waves 4..7 finish on registers), and leave as whole lines
+        // (not with the GELU epilogue: its vector work hides the direct stores, fc1 639 -> 661 us with the image; profiles/r4y_lstore_ab.txt)
+        constexpr bool LSTORE = PP == 1 && !GELU && WTN == 128 && NS * STAGE_BYTES >= NWAVES * 64 * WTN * 2;
+        unsigned char* const ytile = smem + wave * (64 * WTN * 2);
         const int pr = wm * 64 + frow;                       // pixel row of b = 0 inside the tile
         float bia[NG][CPL];
 #pragma unroll
@@ -991,10 +996,28 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                             for (int k = 0; k < 8; ++k) v[k] = FAV_DROP_APPLY(v[k], draws, 8 * h8 + k, p.drop);
                         }
                         const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                        // unconditional: rows beyond M fail the descriptor's range check (the store count stays a constant)
-                        __builtin_amdgcn_raw_buffer_store_b128(o, srd_y1, (ml * p.ldy + n + 8 * h8) * 2, 0, 0);
+                        if (LSTORE) {
+                            const int r = b * 16 + frow, c16 = (g * GS + CPL * fq + 8 * h8) >> 3;   // row / 16-byte chunk inside the wave tile
+                            *(u32x4_t*)(ytile + r * (WTN * 2) + ((c16 ^ (r & 15)) << 4)) = o;
+                        } else {
+                            // unconditional: rows beyond M fail the descriptor's range check (the store count stays a constant)
+                            __builtin_amdgcn_raw_buffer_store_b128(o, srd_y1, (ml * p.ldy + n + 8 * h8) * 2, 0, 0);
+                        }
                     }
                 }
+            }
+        }
+        if (LSTORE && !p.out_f32) {
+            // the wave's 64 x WTN sub-tile leaves in WHOLE 128-byte lines: read back from its private LDS image in line order, one store
+            // instruction = 4 rows x 256 contiguous bytes, instead of 16 rows x four 16-byte pieces at a 32-byte pitch (two instructions
+            // per line) straight from the accumulator layout - the store path is priced per line touched (the tail kernel's LINEST)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int CH = WTN / 8, RPI = 64 / CH;
+#pragma unroll
+            for (int i = 0; i < 64 / RPI; ++i) {
+                const int r = i * RPI + lane / CH, c = lane % CH;
+                const u32x4_t o = *(const u32x4_t*)(ytile + r * (WTN * 2) + ((c ^ (r & 15)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(o, srd_y1, ((wm * 64 + r) * p.ldy + n0 + wn * WTN + c * 8) * 2, 0, 0);
             }
         }
     } else {
