@@ -133,7 +133,10 @@ def test_conv2d_fused_dropout_mask_is_philox(lib):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("k,stride,pad,kpad,H,W", [(7, 2, 3, 192, 32, 40), (3, 1, 1, 64, 16, 16)])
+@pytest.mark.parametrize("k,stride,pad,kpad,H,W", [(7, 2, 3, 192, 32, 40), (3, 1, 1, 64, 16, 16),
+                                                   (16, 16, 0, 768, 64, 48),     # ViT patch embedding: the 16-byte-piece path
+                                                   (16, 16, 0, 768, 32, 40),     # u8 rows of 120 bytes: the scalar path for u8, pieces for fp32
+                                                   (4, 4, 0, 64, 16, 36)])
 def test_stem_im2col_exact(lib, layout, k, stride, pad, kpad, H, W):
     rng = np.random.default_rng(3)
     n = 3
