@@ -850,8 +850,16 @@ const char* launch_layernorm(fav_handle* h, const void* x, long long ldx, const 
                              int D, float eps, hipStream_t s) {
     if (D % 4 != 0 || D > 1024 || rows < 1) return "layernorm: need D % 4 == 0, D <= 1024";
     Prof pr(h, s, FAV_K_AVGPOOL, 0.0, (double)rows * D * 4);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const uint16_t*)x, ldx, gamma, beta,
-                       (uint16_t*)y, rows, D, eps);
+    const int lnr = (int)FAV_KNOB("FAV_LN_ROWS", 4);    // rows per wave (experiments build: 1 / 2 / 4)
+    if (rows >= 4096 && lnr >= 4)
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, (const uint16_t*)x, ldx, gamma, beta,
+                           (uint16_t*)y, rows, D, eps);
+    else if (rows >= 4096 && lnr >= 2)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, (const uint16_t*)x, ldx, gamma, beta,
+                           (uint16_t*)y, rows, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const uint16_t*)x, ldx, gamma, beta,
+                           (uint16_t*)y, rows, D, eps);
     return nullptr;
 }
 

@@ -32,7 +32,7 @@ def host_f32(t):
     return t.float().cpu().numpy()
 
 
-@pytest.mark.parametrize("rows,D,stride_mul", [(20000, 768, 1), (5, 128, 1), (6, 768, 3), (3, 1024, 1)])
+@pytest.mark.parametrize("rows,D,stride_mul", [(20000, 768, 1), (4099, 768, 2), (4097, 192, 1), (5, 128, 1), (6, 768, 3), (3, 1024, 1)])
 def test_layernorm_bitwise(lib, rows, D, stride_mul):
     rng = np.random.default_rng(rows + D)
     # many rows with different scales: a square root or division that is not correctly rounded shows up as a
