@@ -88,3 +88,27 @@ def test_vit_checkpoints_are_machine_independent():
     pins = json.load(open(path))
     assert weights.make_synthetic_vit("vit_tiny", seed=1)[1]["sha256"] == pins["vit_tiny_seed1"]
     assert weights.make_synthetic_vit("vit_b16", seed=1)[1]["sha256"] == pins["vit_b16_seed1"]
+
+
+def test_attention_key_order_is_a_block_permutation():
+    """Slot order of the second attention product: a permutation inside every 32-key block, identity on the block index,
+    keys 4g .. 4g + 3 and 16 + 4g .. 16 + 4g + 3 in lane group g's eight slots."""
+    for t in (1, 17, 32, 197, 256):
+        order = O.attn_key_order(t)
+        assert order.size == (t + 31) // 32 * 32
+        assert np.array_equal(np.sort(order), np.arange(order.size))
+        assert np.array_equal(order >> 5, np.arange(order.size) >> 5)
+    assert O.attn_key_order(32)[:16].tolist() == [0, 1, 2, 3, 16, 17, 18, 19, 4, 5, 6, 7, 20, 21, 22, 23]
+
+
+def test_attention_does_not_depend_on_how_keys_are_padded():
+    """attention() pads keys to a multiple of 32 with zero probabilities: two token counts with the same real keys and queries
+    give the same rows (what lets the device mask only the last key tile)."""
+    rng = np.random.default_rng(4)
+    qkv = O.bf16_round((rng.standard_normal((1, 40, 3 * 64)) * 1.1).astype(np.float32))
+    full = O.attention(qkv, 1, exact="mfma")
+    again = O.attention(qkv.copy(), 1, exact="mfma")
+    assert np.array_equal(full, again)
+    ref = np.einsum("qk,kd->qd", torch.softmax(torch.from_numpy(qkv[0, :, :64] @ qkv[0, :, 64:128].T).double() / 8, -1).numpy(),
+                    qkv[0, :, 128:].astype(np.float64))
+    assert np.abs(full[0] - ref).max() < 0.03
