@@ -43,6 +43,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// ReLU on a PACKED pair of bf16 values: as signed 16-bit integers every negative float (and -0) is negative, every non-negative one
+// keeps its pattern, so max(x, 0) per half is ONE v_pk_max_i16 for two elements.  Rounding first and clamping afterwards gives the same
+// bits as clamping the fp32 value first: a negative value rounds to a negative bf16 (or -0) and becomes +0 either way.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, v), (s16x2_t){0, 0}));
+}
 
 // fp32 frames come from the caller: a NaN pixel counts as 0, everything else is clamped to [-64, 64] (far outside any image range;
 // pixels in [0, 1] pass unchanged), so that no garbage frame can put a NaN or an infinity into the network - the reference's seam
@@ -446,9 +453,9 @@ __global__ __launch_bounds__(256, 2) void stem7_pool_kernel(StemPoolParams p) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const float4 bq = *(const float4*)(bias_s + 16 * a + 4 * fq);
-                const float v0 = fmaxf(__fadd_rn(acc[a][0], bq.x), 0.f), v1 = fmaxf(__fadd_rn(acc[a][1], bq.y), 0.f);
-                const float v2 = fmaxf(__fadd_rn(acc[a][2], bq.z), 0.f), v3 = fmaxf(__fadd_rn(acc[a][3], bq.w), 0.f);
-                *(uint2*)(crow + (((2 * a + (fq >> 1)) ^ (q & 7)) << 4)) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                const float v0 = __fadd_rn(acc[a][0], bq.x), v1 = __fadd_rn(acc[a][1], bq.y);
+                const float v2 = __fadd_rn(acc[a][2], bq.z), v3 = __fadd_rn(acc[a][3], bq.w);
+                *(uint2*)(crow + (((2 * a + (fq >> 1)) ^ (q & 7)) << 4)) = make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
             }
         }
         __syncthreads();
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
                             v[2 * k + 1] = __fadd_rn(v[2 * k + 1], bf16_bits_to_f32(rw[k] >> 16));
                         }
                     }
-                    if (p.relu == 1) {
+                    if (p.relu == 1 && p.out_f32) {        // (bf16 output: ReLU on the packed pairs below)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
                     } else if (GELU && p.relu == 2) {
@@ -1040,7 +1047,11 @@ __global__ __launch_bounds__((BM / 64) * WN * 64, OCCW ? OCCW : conv_waves_per_s
 #pragma unroll
                             for (int k = 0; k < 8; ++k) v[k] = FAV_DROP_APPLY(v[k], draws, 8 * h8 + k, p.drop);
                         }
-                        const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        if (p.relu == 1) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) o[k] = relu_bf16x2(o[k]);
+                        }
                         if (LSTORE) {
                             const int r = b * 16 + frow, c16 = (g * GS + CPL * fq + 8 * h8) >> 3;   // row / 16-byte chunk inside the wave tile
                             *(u32x4_t*)(ytile + r * (WTN * 2) + ((c16 ^ (r & 15)) << 4)) = o;
@@ -1881,10 +1892,11 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 const int row = wm * 64 + b * 16 + frow;
                 const int c0 = wn * (CMID / WN1) + a * 16 + fq * 4;
                 const float4 bq = *(const float4*)(bias_b_s + (c0 >> 4) * 20 + (c0 & 15));
-                const float v0 = fmaxf(__fadd_rn(acc[a][b][0], bq.x), 0.f), v1 = fmaxf(__fadd_rn(acc[a][b][1], bq.y), 0.f);
-                const float v2 = fmaxf(__fadd_rn(acc[a][b][2], bq.z), 0.f), v3 = fmaxf(__fadd_rn(acc[a][b][3], bq.w), 0.f);
+                const float v0 = __fadd_rn(acc[a][b][0], bq.x), v1 = __fadd_rn(acc[a][b][1], bq.y);
+                const float v2 = __fadd_rn(acc[a][b][2], bq.z), v3 = __fadd_rn(acc[a][b][3], bq.w);
                 const int sw = tail_sw<CPR>(row);
-                *(uint2*)(tsm + row * ROWB + (((c0 >> 3) ^ sw) << 4) + ((c0 >> 2) & 1) * 8) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                *(uint2*)(tsm + row * ROWB + (((c0 >> 3) ^ sw) << 4) + ((c0 >> 2) & 1) * 8) =
+                    make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
             }
     }
     // wave w owns pixel rows [w*RP, w*RP + RP): their T2 fragments (all CMID k) live in registers from here on
@@ -2057,15 +2069,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                             v[2 * k + 1] = __fadd_rn(v[2 * k + 1], bf16_bits_to_f32(rw[k] >> 16));
                         }
                     }
-                    if (RELU) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                    }
                     if (p.drop.site >= 0) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = FAV_DROP_APPLY(v[k], draws, 8 * g + k, p.drop);
                     }
-                    const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    if (RELU) {      // on the packed pairs: half the instructions of eight v_max_f32 (scale > 0: the sign is the value's own)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = relu_bf16x2(o[k]);
+                    }
                     if (!LINEST) __builtin_amdgcn_raw_buffer_store_b128(o, srd_y, (row * COUT + n + 8 * g) * 2, 0, 0);
                     if (LINEST) *(u32x4_t*)(ych + row * 128 + (((2 * fq + g) ^ (row & 7)) << 4)) = o;
                 }
@@ -2149,8 +2161,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_tail_kernel(const TailP
                 for (int g = 0; g < 2; ++g) {
                     float v[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(__fadd_rn(acc3[g3 * 4 + 2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]), 0.f);
-                    const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc3[g3 * 4 + 2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]);
+                    const u32x4_t o = {relu_bf16x2(pack_bf16x2(v[0], v[1])), relu_bf16x2(pack_bf16x2(v[2], v[3])), relu_bf16x2(pack_bf16x2(v[4], v[5])),
+                                       relu_bf16x2(pack_bf16x2(v[6], v[7]))};
                     __builtin_amdgcn_raw_buffer_store_b128(o, srd_t, (row * NRED + g3 * 64 + fq * 16 + 8 * g) * 2, 0, 0);
                 }
             }
@@ -2436,8 +2449,9 @@ __global__ __launch_bounds__(256, 2) void entry_reduce_kernel(const EntryReduceP
                 for (int g = 0; g < 2; ++g) {
                     float v[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(__fadd_rn(acc3[g3 * 4 + 2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]), 0.f);
-                    const u32x4_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    for (int k = 0; k < 8; ++k) v[k] = __fadd_rn(acc3[g3 * 4 + 2 * g + (k >> 2)][b][k & 3], bia[8 * g + k]);
+                    const u32x4_t o = {relu_bf16x2(pack_bf16x2(v[0], v[1])), relu_bf16x2(pack_bf16x2(v[2], v[3])), relu_bf16x2(pack_bf16x2(v[4], v[5])),
+                                       relu_bf16x2(pack_bf16x2(v[6], v[7]))};
                     __builtin_amdgcn_raw_buffer_store_b128(o, srd_t, (int)(orow[b] * (uint32_t)(NRED * 2)) + (g3 * 64 + fq * 16 + 8 * g) * 2, 0, 0);
                 }
         }
